@@ -1,0 +1,35 @@
+# Top-level build: host library, HIP library (gfx950), oracle (test-only).
+#   make host     -> raytracer_amd/libraytracer_host.so   (scene loader, PNG I/O; no GPU)
+#   make hip      -> raytracer_amd/librt_hip.so           (HIP kernels + C ABI of include/rt_hip.h)
+#   make cli      -> raytracer_amd/rt_amd                 (reference-compatible driver)
+#   make oracle   -> oracle/liboracle.so (+ oracle/_ref when /root/reference exists)
+CXX      ?= g++
+HIPCC    ?= /opt/rocm/bin/hipcc
+HOSTFLAGS = -O2 -std=c++17 -pthread -ffp-contract=off -fPIC -Wall -Wextra
+HOST_SRCS = raytracer_amd/host/scene_loader.cpp raytracer_amd/host/png_io.cpp raytracer_amd/host/host_capi.cpp
+HOST_HDRS = $(wildcard raytracer_amd/host/*.h) include/rt_hip.h
+HIPFLAGS  = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall
+
+all: host hip cli oracle
+
+host: raytracer_amd/libraytracer_host.so
+raytracer_amd/libraytracer_host.so: $(HOST_SRCS) $(HOST_HDRS)
+	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRCS) -lz
+
+hip: raytracer_amd/librt_hip.so
+raytracer_amd/librt_hip.so: $(wildcard raytracer_amd/csrc/*.hip) $(wildcard raytracer_amd/csrc/*.h) include/rt_hip.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(wildcard raytracer_amd/csrc/*.hip)
+
+cli: raytracer_amd/rt_amd
+raytracer_amd/rt_amd: $(wildcard raytracer_amd/host/*.cpp) $(HOST_HDRS) raytracer_amd/librt_hip.so
+	$(CXX) $(HOSTFLAGS) -o $@ raytracer_amd/host/cli_main.cpp raytracer_amd/host/tracer_shim.cpp \
+	    raytracer_amd/host/scene_loader.cpp raytracer_amd/host/png_io.cpp \
+	    -Lraytracer_amd -lrt_hip -lz -Wl,-rpath,'$$ORIGIN'
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f raytracer_amd/*.so raytracer_amd/rt_amd
+	$(MAKE) -C oracle clean
+.PHONY: all host hip cli oracle clean

@@ -1,0 +1,231 @@
+/*
+ * rt_hip.h — C ABI of the MI355X (gfx950) trace path.
+ *
+ * This is the drop-in boundary for the two calls the reference's render loops make
+ * (reference src/main.cpp:18-24,59-63,100-104,142-146):
+ *
+ *     PhotonMapper::generate(scene);                 // reference src/photonmap.h:7
+ *     const Picture p = raytracer.raytrace(scene);   // reference src/raytracer.h:9
+ *
+ * Everything crossing the boundary is plain C: POD structs, pointers and sizes.  No HIP, torch or
+ * C++ types appear in any signature.  Every entry point returns RT_OK (0) or a negative rt_status;
+ * none throws or aborts.  The message for the last failure on a context is rt_last_error(ctx)
+ * (rt_last_error(NULL) for a failed rt_create).  Reference behaviour replaced: std::runtime_error
+ * caught once in main (reference src/main.cpp:202-205).
+ *
+ * Threading: calls on one rt_ctx are serialised by the caller.  Different contexts (one per GPU)
+ * may be driven from different host threads or processes.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = -1,
+    RT_ERR_NO_DEVICE = -2,      /* HIP runtime/device missing: the product path never falls back to CPU */
+    RT_ERR_HIP = -3,            /* a HIP call failed; text in rt_last_error */
+    RT_ERR_NO_SCENE = -4,       /* render/photon call before rt_scene_upload */
+    RT_ERR_LIMIT = -5           /* a size is beyond what the kernels were built for */
+} rt_status;
+
+/* ---- scene description (input of the boundary; reference src/scene.h:14-30 getters) ---------- */
+
+/* Row-major 3x4 affine matrix, last row implied (0,0,0,1).  reference src/types.h:116-117 */
+typedef struct rt_mat34 { float m[12]; } rt_mat34;
+
+/* reference src/objects.h:165-205 (Camera) */
+typedef struct rt_camera {
+    rt_mat34 camera_to_world;   /* Matrix34::lookAt(position, lookAt, up), src/types.h:176-186 */
+    float    fov;               /* radians; the trace path uses it as a HALF angle, src/raytracer.cpp:23-24 */
+    uint32_t width, height;     /* resolution */
+    uint32_t supersampling;     /* sub-pixels per axis (>=1) */
+    uint32_t max_bounces;
+    float    focus_distance;    /* |focusPoint - position|, src/objects.h:191 */
+    float    lens_size;         /* 0 = pinhole */
+} rt_camera;
+
+enum { RT_LIGHT_PARALLEL = 0, RT_LIGHT_POINT = 1 };   /* reference src/objects.h:140-143 */
+typedef struct rt_light {
+    int32_t type;
+    float   position[3];        /* direction for a parallel light, src/objects.h:155-156 */
+    float   power[4];           /* RGBA */
+} rt_light;
+
+/* reference src/objects.h:18-31 (Material); the texture Picture is replaced by an index */
+typedef struct rt_material {
+    float   color[4];
+    int32_t texture;            /* index into textures, -1 = none (then `color` is used) */
+    float   ka, kd, ks, exponent;
+    float   reflectance, transmittance;   /* on/off switches only, src/raytracer.cpp:151-158 */
+    float   refraction_re, refraction_im; /* complex index of refraction */
+    float   dispersion;
+} rt_material;
+
+/* RGBA8 texture; float texel = u8/255.0f (reference src/types.h:272) */
+typedef struct rt_texture {
+    uint32_t width, height;
+    uint64_t offset;            /* byte offset of texel (0,0) in rt_scene_desc.texels; rows top-down */
+} rt_texture;
+
+/* reference src/objects.h:34-56 */
+typedef struct rt_sphere {
+    float    center[3];
+    float    radius;
+    rt_mat34 world_to_object, object_to_world, object_to_world_normals;
+} rt_sphere;
+
+/* reference src/objects.h:58-74; vertices are already in world space (src/wavefobj.cpp:82-106) */
+typedef struct rt_triangle {
+    float position[3][3];
+    float normal[3][3];
+    float uv[3][2];
+} rt_triangle;
+
+/* reference src/objects.h:76-102 */
+typedef struct rt_julia {
+    float    position[3];
+    float    scale;
+    float    c[4];              /* quaternion r,a,b,c */
+    float    cut_plane;
+    rt_mat34 world_to_object, object_to_world, object_to_world_normals;
+} rt_julia;
+
+enum { RT_OBJ_SPHERE = 0, RT_OBJ_TRIANGLE = 1, RT_OBJ_JULIA = 2 };
+/* One entry per element of Scene::objects(), IN SCENE ORDER (ties between equally distant hits go
+ * to the later object, reference src/raytracer.cpp:126-141). */
+typedef struct rt_object {
+    int32_t  kind;              /* RT_OBJ_* */
+    uint32_t index;             /* into spheres / triangles / julias */
+    uint32_t material;          /* into materials */
+} rt_object;
+
+typedef struct rt_scene_desc {
+    uint32_t abi_version;       /* RT_ABI_VERSION */
+    rt_camera camera;
+    float    background[4];
+    float    ambient[4];
+    uint32_t n_lights;     const rt_light*    lights;
+    uint32_t n_objects;    const rt_object*   objects;
+    uint32_t n_spheres;    const rt_sphere*   spheres;
+    uint32_t n_triangles;  const rt_triangle* triangles;
+    uint32_t n_julias;     const rt_julia*    julias;
+    uint32_t n_materials;  const rt_material* materials;
+    uint32_t n_textures;   const rt_texture*  textures;
+    uint64_t n_texel_bytes; const uint8_t*    texels;
+    int32_t  dispersion_mode;   /* any(material.dispersion != 0), reference src/sceneparser.cpp:63-67 */
+    /* RGB of HSVtoRGB(h,100,100) for h = 0,45,...,315.  DATA, not code: the reference's table
+     * depends on how it is compiled (src/types.h:318, unqualified abs).  See rt_hue_table(). */
+    float    hue_rgb[8][3];
+    float    photon_steps;      /* <caustic steps>; 0 = no photon pass */
+    uint32_t photon_texture_size;
+    float    photon_factor;
+} rt_scene_desc;
+
+enum { RT_HUE_INT_ABS = 0, RT_HUE_FLOAT_ABS = 1 };
+/* Fills one of the two named presets of the dispersion hue table (int-abs is what both pinned
+ * reference builds produce). */
+int rt_hue_table(int preset, float out_rgb[8][3]);
+
+/* ---- work partition ------------------------------------------------------------------------- */
+
+/* Horizontal bands of `band_rows` image rows; this call renders bands first_band, first_band +
+ * band_stride, ...  The output buffer is COMPACT: the rendered bands back to back, each band
+ * band_rows*width RGBA float pixels (the last band of the image may be shorter).  NULL = whole image.
+ * No counterpart in the reference (its row scheduler is src/raytracer.cpp:48-53). */
+typedef struct rt_bands {
+    uint32_t band_rows;
+    uint32_t first_band;
+    uint32_t band_stride;
+} rt_bands;
+
+/* Number of RGBA float pixels rt_render writes for this partition of a width x height image. */
+uint64_t rt_bands_pixel_count(uint32_t width, uint32_t height, const rt_bands* bands_or_null);
+
+/* ---- counters ------------------------------------------------------------------------------- */
+
+typedef struct rt_stats {
+    uint64_t primary_rays;          /* depth-0 castRay calls */
+    uint64_t secondary_rays;        /* reflection + refraction castRay calls */
+    uint64_t shadow_rays;
+    uint64_t photon_segments;       /* PhotonMapper::castRay calls */
+    uint64_t photon_deposits;
+    uint64_t sphere_tests;
+    uint64_t triangle_tests;
+    uint64_t julia_queries;         /* Julia::intersect calls */
+    uint64_t julia_steps;           /* march steps == full-iteration DE calls */
+    uint64_t julia_de_iterations;   /* quaternion iterations incl. the 6x8-capped normal probes */
+    uint64_t julia_normals;
+    uint64_t shaded_hits;           /* accepted nearest hits that were shaded */
+    uint64_t phong_lights;          /* per-light Phong evaluations (each casts one shadow ray) */
+    uint64_t fresnel_evals;
+    uint64_t texture_lookups;
+    uint64_t bvh_node_visits;
+    double   kernel_ms;             /* device time of the last call's kernels (HIP events) */
+} rt_stats;
+
+/* ---- context -------------------------------------------------------------------------------- */
+
+typedef struct rt_ctx rt_ctx;
+
+int  rt_create(rt_ctx** out_ctx, int device_id);
+void rt_destroy(rt_ctx* ctx);
+const char* rt_last_error(const rt_ctx* ctx_or_null);
+
+/* Deep-copies the scene to the device (the caller keeps ownership of every pointer in `desc`),
+ * builds the triangle BVH on the GPU and clears the photon atlas.  Replaces the `const Scene&`
+ * argument of reference src/raytracer.h:9. */
+int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* desc);
+
+/* Options that are not part of the scene (never read from scene XML). */
+enum {
+    RT_OPT_COLLECT_STATS = 1,   /* 0/1: fill rt_stats counters (slower kernels); default 0 */
+    RT_OPT_BVH_MIN_TRIANGLES = 2,/* use BVH traversal for triangle runs of at least this many; default 64 */
+    RT_OPT_DOF_SEED = 3         /* seed of the counter-based lens RNG; default 0 */
+};
+int rt_set_option(rt_ctx* ctx, int option, int64_t value);
+
+/* ≙ PhotonMapper::generate(Scene&)  (reference src/photonmap.cpp:16-59).  The photon textures stay
+ * on the device and are read by the next rt_render.  No-op when photon_steps <= 0. */
+int rt_photon_generate(rt_ctx* ctx, rt_stats* stats_or_null);
+
+/* ≙ Picture RayTracer::raytrace(const Scene&)  (reference src/raytracer.cpp:10-15).  Synchronous.
+ * `rgba_out` is caller-owned HOST memory of rt_bands_pixel_count()*4 floats, row-major RGBA, the
+ * layout of Picture (reference src/types.h:385). */
+int rt_render(rt_ctx* ctx, const rt_bands* bands_or_null, float* rgba_out, rt_stats* stats_or_null);
+
+/* Same, but `d_rgba_out` is DEVICE memory on the context's GPU and the kernels are enqueued on
+ * `hip_stream` (a hipStream_t passed as void*, NULL = the default stream) without synchronising.
+ * This is the entry point the multi-GPU driver uses so that frames stay in HBM for the RCCL gather.
+ * stats (if requested) are valid after the stream has been synchronised by the caller and
+ * rt_fetch_stats is called. */
+int rt_render_device(rt_ctx* ctx, const rt_bands* bands_or_null, void* d_rgba_out, void* hip_stream);
+int rt_photon_generate_device(rt_ctx* ctx, void* hip_stream);
+int rt_fetch_stats(rt_ctx* ctx, rt_stats* out);
+
+/* Test hook: copies the photon texture of scene object `object_index` (texture_size^2 RGBA floats;
+ * zeros if the object is not a diffuse receiver).  ≙ Object::getPhoton, reference src/objects.cpp:257-267 */
+int rt_photon_download(rt_ctx* ctx, uint32_t object_index, float* rgba_out);
+
+/* ≙ Picture::mulAdd (reference src/types.h:372-376): d_acc[i] += d_src[i] * factor over n_floats
+ * device floats, on `hip_stream`.  Motion-blur accumulation (reference src/main.cpp:64,147). */
+int rt_mul_add_device(rt_ctx* ctx, void* d_acc, const void* d_src, float factor, uint64_t n_floats,
+                      void* hip_stream);
+
+/* ≙ Color::scaleOut (reference src/types.h:274-282): RGBA float -> RGBA8 by
+ * u8(clamp(v*gain,0,1)*255.0f), truncating.  n_pixels pixels, device to device. */
+int rt_quantize_device(rt_ctx* ctx, const void* d_rgba, void* d_rgba8, float gain, uint64_t n_pixels,
+                       void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

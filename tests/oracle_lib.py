@@ -1,0 +1,88 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE (the checker, never the product)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from raytracer_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_LIB_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        l = C.CDLL(ORACLE_LIB_PATH)
+        l.oracle_photon_generate.restype = C.c_void_p
+        l.oracle_photon_generate.argtypes = [C.POINTER(capi.SceneDesc), C.POINTER(capi.Stats)]
+        l.oracle_photon_free.argtypes = [C.c_void_p]
+        l.oracle_photon_get.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        l.oracle_render.argtypes = [C.POINTER(capi.SceneDesc), C.c_void_p, C.c_int, C.c_void_p, C.POINTER(capi.Stats)]
+        l.oracle_render_rows.argtypes = [C.POINTER(capi.SceneDesc), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_int, C.c_void_p, C.POINTER(capi.Stats)]
+        l.oracle_intersect.argtypes = [C.POINTER(capi.SceneDesc), C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        l.oracle_fresnel.restype = C.c_float
+        l.oracle_fresnel.argtypes = [C.POINTER(capi.Material), C.c_float, C.c_float]
+        l.oracle_cast_ray.argtypes = [C.POINTER(capi.SceneDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        l.oracle_camera_ray.argtypes = [C.POINTER(capi.SceneDesc), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        l.oracle_photon_scan.argtypes = [C.c_float, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.POINTER(C.c_uint32)]
+        _lib = l
+    return _lib
+
+
+class Photons:
+    def __init__(self, scene):
+        self.stats = capi.Stats()
+        self.scene = scene
+        self._h = lib().oracle_photon_generate(C.byref(scene.desc), C.byref(self.stats))
+
+    def texture(self, object_index):
+        size = self.scene.desc.photon_texture_size
+        out = np.zeros((size, size, 4), dtype=np.float32)
+        lib().oracle_photon_get(self._h, object_index, out.ctypes.data)
+        return out
+
+    def __del__(self):
+        if self._h:
+            lib().oracle_photon_free(self._h)
+            self._h = None
+
+
+def render(scene, photons=None, threads=8, rows=None):
+    """Oracle render; rows=(begin,end,step) restricts the rows computed (others stay zero)."""
+    cam = scene.desc.camera
+    out = np.zeros((cam.height, cam.width, 4), dtype=np.float32)
+    st = capi.Stats()
+    b, e, s = rows if rows else (0, cam.height, 1)
+    lib().oracle_render_rows(C.byref(scene.desc), photons._h if photons else None, b, e, s, threads,
+                             out.ctypes.data, C.byref(st))
+    return out, st
+
+
+def intersect(scene, object_index, origin, direction, max_distance):
+    o = np.asarray(origin, dtype=np.float32)
+    d = np.asarray(direction, dtype=np.float32)
+    out = np.zeros(11, dtype=np.float32)
+    hit = lib().oracle_intersect(C.byref(scene.desc), object_index, o.ctypes.data, d.ctypes.data, max_distance,
+                                 out.ctypes.data)
+    return bool(hit), out
+
+
+def fresnel(material, cos_rn, wavelength):
+    return lib().oracle_fresnel(C.byref(material), cos_rn, wavelength)
+
+
+def image_diff(a8, b8):
+    """Parity metric of BASELINE.json: fraction of pixels with any channel off by >1 LSB, max abs
+    difference, PSNR (dB) over all channels."""
+    a = a8.astype(np.int32)
+    b = b8.astype(np.int32)
+    d = np.abs(a - b)
+    per_pixel = d.reshape(-1, d.shape[-1]).max(axis=1)
+    mse = float((d.astype(np.float64) ** 2).mean())
+    psnr = float("inf") if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
+    return {"max": int(d.max()), "frac_gt0": float((per_pixel > 0).mean()), "frac_gt1": float((per_pixel > 1).mean()),
+            "psnr": psnr}
