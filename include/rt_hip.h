@@ -225,6 +225,16 @@ int rt_mul_add_device(rt_ctx* ctx, void* d_acc, const void* d_src, float factor,
 int rt_quantize_device(rt_ctx* ctx, const void* d_rgba, void* d_rgba8, float gain, uint64_t n_pixels,
                        void* hip_stream);
 
+/* ---- test hooks -------------------------------------------------------------------------------
+ * One function of the path per call, for the known-answer parity tests (tests/test_gpu_kat.py).
+ * rt_kat_intersect ≙ Object::intersect (reference src/objects.h:124-126): n rays of 7 floats
+ * (origin, direction as given to the Ray constructor, max_distance) against scene object
+ * object_index[i]; out = 12 floats per ray (hit flag, distance, point, normal, uv, photon uv).
+ * rt_kat_fresnel ≙ calcFresnel (reference src/raytracer.cpp:243-268): n records of 5 floats
+ * (refraction re, im, dispersion, cos, wavelength); out = kr per record. */
+int rt_kat_intersect(rt_ctx* ctx, const uint32_t* object_index, const float* rays, uint32_t n, float* out);
+int rt_kat_fresnel(rt_ctx* ctx, const float* records, uint32_t n, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,733 @@
+// rt_api.hip — host side of the C ABI declared in include/rt_hip.h.
+//
+// Owns the device copy of the scene (layout: rt_scene_dev.h), precomputes on the host the few
+// constants the reference computes once per frame (camera frame src/raytracer.cpp:17-29, the rayX
+// row table :59/:111, the photon scan tables src/photonmap.cpp:38-45) and launches the kernels of
+// rt_kernels.hip.  No CPU fallback exists: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_scene_dev.h"
+
+namespace rtd {
+template <bool HAS_JULIA, bool STATS>
+__global__ void trace_kernel(const DevScene sc, const DevJob job);
+template <bool HAS_JULIA, bool STATS>
+__global__ void photon_kernel(const DevScene sc, const DevPhotonJob job);
+__global__ void sum_samples_kernel(const float4* samples, float4* out, unsigned long long n_pixels, unsigned samples_per_pixel, float inv_samples);
+__global__ void kat_intersect_kernel(const DevScene sc, const unsigned* kind, const unsigned* prim, const float* rays, unsigned n, float* out);
+__global__ void kat_fresnel_kernel(const float* in, unsigned n, float* out);
+__global__ void mul_add_kernel(float* acc, const float* src, float factor, unsigned long long n);
+__global__ void quantize_kernel(const float4* rgba, uchar4* out, float gain, unsigned long long n);
+constexpr int kFrameFieldsHost = 11;
+}  // namespace rtd
+
+using namespace rtd;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Buffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    int n_cus = 0;
+    std::string error;
+    bool has_scene = false;
+    DevScene dev{};
+    std::vector<void*> scene_allocs;
+    // host-side facts about the uploaded scene
+    uint32_t n_objects = 0, n_slots = 0;
+    std::vector<int32_t> photon_slot;
+    std::vector<uint32_t> object_kind, object_prim;
+    std::vector<uint32_t> point_lights;
+    float photon_steps = 0.0f;
+    uint32_t hues = 1;
+    // photon tables
+    Buffer photon_tables;
+    uint32_t n_phi = 0, n_theta = 0;
+    uint32_t* d_point_lights = nullptr;
+    // options
+    bool collect_stats = false;
+    int64_t bvh_min_triangles = 64;
+    uint32_t dof_seed = 0;
+    // per-call scratch, grown on demand and kept
+    Buffer samples, stack, out_staging, kat_a, kat_b, kat_c, kat_d;
+    unsigned long long* d_queue = nullptr;      // [0] = queue head
+    unsigned long long* d_counters = nullptr;   // rt_stats words
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool events_pending = false;
+};
+
+namespace {
+
+int fail(rt_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->error = buf; else g_create_error = buf;
+    return code;
+}
+
+#define RT_HIP_TRY(ctx, expr)                                                                          \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(ctx, RT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
+
+int grow(rt_ctx* ctx, Buffer& b, size_t bytes) {
+    if (b.bytes >= bytes && b.ptr) return RT_OK;
+    if (b.ptr) RT_HIP_TRY(ctx, hipFree(b.ptr));
+    b.ptr = nullptr;
+    b.bytes = 0;
+    RT_HIP_TRY(ctx, hipMalloc(&b.ptr, bytes));
+    b.bytes = bytes;
+    return RT_OK;
+}
+
+template <typename T>
+int upload(rt_ctx* ctx, const std::vector<T>& host, const T** out) {
+    *out = nullptr;
+    const size_t bytes = (host.empty() ? 1 : host.size()) * sizeof(T);
+    void* d = nullptr;
+    RT_HIP_TRY(ctx, hipMalloc(&d, bytes));
+    ctx->scene_allocs.push_back(d);
+    if (!host.empty()) RT_HIP_TRY(ctx, hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(d);
+    return RT_OK;
+}
+
+void free_scene(rt_ctx* ctx) {
+    for (void* p : ctx->scene_allocs) (void)hipFree(p);
+    ctx->scene_allocs.clear();
+    ctx->has_scene = false;
+}
+
+// tiles / samples of one render call
+void make_job(const rt_ctx* ctx, const rt_bands* bands, DevJob* job) {
+    const DevScene& sc = ctx->dev;
+    rt_bands b = {sc.height ? sc.height : 1u, 0u, 1u};
+    if (bands) b = *bands;
+    std::memset(job, 0, sizeof *job);
+    job->band_rows = b.band_rows;
+    job->first_band = b.first_band;
+    job->band_stride = b.band_stride;
+    job->n_pixels = rt_bands_pixel_count(sc.width, sc.height, &b);
+    job->compact_rows = sc.width ? static_cast<uint32_t>(job->n_pixels / sc.width) : 0;
+    job->tiles_x = (sc.width + 7) / 8;
+    job->tiles_y = (job->compact_rows + 7) / 8;
+    job->samples_per_pixel = sc.supersampling * sc.supersampling * (sc.dispersion ? 8u : 1u);
+    job->n_samples = static_cast<uint64_t>(job->tiles_x) * job->tiles_y * job->samples_per_pixel * 64ull;
+    job->dof_seed = ctx->dof_seed;
+}
+
+template <typename K>
+int persistent_grid(rt_ctx* ctx, K kernel, uint64_t work_items, int* blocks) {
+    int per_cu = 0;
+    RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0));
+    if (per_cu < 1) per_cu = 1;
+    uint64_t g = static_cast<uint64_t>(ctx->n_cus) * per_cu;
+    const uint64_t needed = (work_items + 255) / 256;
+    if (g > needed) g = needed;
+    if (g < 1) g = 1;
+    *blocks = static_cast<int>(g);
+    return RT_OK;
+}
+
+int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_t stream) {
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_render before rt_scene_upload");
+    if (bands && (bands->band_rows == 0 || bands->band_stride == 0)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_bands: band_rows and band_stride must be > 0");
+    DevJob job;
+    make_job(ctx, bands, &job);
+    if (job.n_pixels == 0) return RT_OK;
+    const bool julia = ctx->dev.n_julias > 0;
+    const bool stats = ctx->collect_stats;
+    int blocks = 0;
+    int rc;
+    if (julia) rc = stats ? persistent_grid(ctx, trace_kernel<true, true>, job.n_samples, &blocks) : persistent_grid(ctx, trace_kernel<true, false>, job.n_samples, &blocks);
+    else rc = stats ? persistent_grid(ctx, trace_kernel<false, true>, job.n_samples, &blocks) : persistent_grid(ctx, trace_kernel<false, false>, job.n_samples, &blocks);
+    if (rc != RT_OK) return rc;
+    const uint64_t lanes = static_cast<uint64_t>(blocks) * 256;
+    rc = grow(ctx, ctx->stack, lanes * (ctx->dev.max_bounces + 1) * kFrameFieldsHost * sizeof(float));
+    if (rc != RT_OK) return rc;
+    if (job.samples_per_pixel > 1) {
+        rc = grow(ctx, ctx->samples, job.n_pixels * job.samples_per_pixel * sizeof(float4));
+        if (rc != RT_OK) return rc;
+        job.samples = static_cast<float4*>(ctx->samples.ptr);
+    }
+    job.out = d_out;
+    job.stack = static_cast<float*>(ctx->stack.ptr);
+    job.queue_head = ctx->d_queue;
+    job.counters = ctx->d_counters;
+    RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), stream));
+    RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long), stream));
+    RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
+    if (julia) {
+        if (stats) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, ctx->dev, job);
+        else hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, ctx->dev, job);
+    } else {
+        if (stats) hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, ctx->dev, job);
+        else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, ctx->dev, job);
+    }
+    RT_HIP_TRY(ctx, hipGetLastError());
+    if (job.samples_per_pixel > 1) {
+        const unsigned g = static_cast<unsigned>((job.n_pixels + 255) / 256);
+        hipLaunchKernelGGL(sum_samples_kernel, dim3(g), dim3(256), 0, stream, job.samples, job.out, job.n_pixels, job.samples_per_pixel, ctx->dev.inv_samples);
+        RT_HIP_TRY(ctx, hipGetLastError());
+    }
+    RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream));
+    ctx->events_pending = true;
+    return RT_OK;
+}
+
+int photon_enqueue(rt_ctx* ctx, hipStream_t stream) {
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_photon_generate before rt_scene_upload");
+    RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long), stream));
+    RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
+    if (ctx->photon_steps > 0.0f && ctx->n_slots > 0 && !ctx->point_lights.empty() && ctx->n_phi > 0 && ctx->n_theta > 0) {
+        const size_t atlas_bytes = static_cast<size_t>(ctx->n_slots) * ctx->dev.photon_size * ctx->dev.photon_size * sizeof(float4);
+        RT_HIP_TRY(ctx, hipMemsetAsync(ctx->dev.photon_atlas, 0, atlas_bytes, stream));
+        DevPhotonJob job{};
+        const float* t = static_cast<const float*>(ctx->photon_tables.ptr);
+        job.sin_phi = t;
+        job.cos_phi = t + ctx->n_phi;
+        job.sin_theta = t + 2 * ctx->n_phi;
+        job.cos_theta = t + 2 * ctx->n_phi + ctx->n_theta;
+        job.n_phi = ctx->n_phi;
+        job.n_theta = ctx->n_theta;
+        job.n_point_lights = static_cast<uint32_t>(ctx->point_lights.size());
+        job.point_lights = ctx->d_point_lights;
+        job.hues = ctx->hues;
+        job.n_roots = static_cast<uint64_t>(job.n_point_lights) * job.n_phi * job.n_theta * job.hues;
+        const bool julia = ctx->dev.n_julias > 0;
+        const bool stats = ctx->collect_stats;
+        int blocks = 0;
+        int rc;
+        if (julia) rc = stats ? persistent_grid(ctx, photon_kernel<true, true>, job.n_roots, &blocks) : persistent_grid(ctx, photon_kernel<true, false>, job.n_roots, &blocks);
+        else rc = stats ? persistent_grid(ctx, photon_kernel<false, true>, job.n_roots, &blocks) : persistent_grid(ctx, photon_kernel<false, false>, job.n_roots, &blocks);
+        if (rc != RT_OK) return rc;
+        const uint64_t lanes = static_cast<uint64_t>(blocks) * 256;
+        rc = grow(ctx, ctx->stack, lanes * (ctx->dev.max_bounces + 1) * kFrameFieldsHost * sizeof(float));
+        if (rc != RT_OK) return rc;
+        job.stack = static_cast<float*>(ctx->stack.ptr);
+        job.queue_head = ctx->d_queue;
+        job.counters = ctx->d_counters;
+        RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), stream));
+        if (julia) {
+            if (stats) hipLaunchKernelGGL((photon_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, ctx->dev, job);
+            else hipLaunchKernelGGL((photon_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, ctx->dev, job);
+        } else {
+            if (stats) hipLaunchKernelGGL((photon_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, ctx->dev, job);
+            else hipLaunchKernelGGL((photon_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, ctx->dev, job);
+        }
+        RT_HIP_TRY(ctx, hipGetLastError());
+    }
+    RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream));
+    ctx->events_pending = true;
+    return RT_OK;
+}
+
+int read_stats(rt_ctx* ctx, rt_stats* out) {
+    if (out == nullptr) return RT_OK;
+    std::memset(out, 0, sizeof *out);
+    unsigned long long c[C_COUNT];
+    RT_HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    out->primary_rays = c[C_PRIMARY];
+    out->secondary_rays = c[C_SECONDARY];
+    out->shadow_rays = c[C_SHADOW];
+    out->photon_segments = c[C_PHOTON_SEGMENTS];
+    out->photon_deposits = c[C_PHOTON_DEPOSITS];
+    out->sphere_tests = c[C_SPHERE_TESTS];
+    out->triangle_tests = c[C_TRIANGLE_TESTS];
+    out->julia_queries = c[C_JULIA_QUERIES];
+    out->julia_steps = c[C_JULIA_STEPS];
+    out->julia_de_iterations = c[C_JULIA_DE_ITERATIONS];
+    out->julia_normals = c[C_JULIA_NORMALS];
+    out->shaded_hits = c[C_SHADED_HITS];
+    out->phong_lights = c[C_PHONG_LIGHTS];
+    out->fresnel_evals = c[C_FRESNEL];
+    out->texture_lookups = c[C_TEXTURE_LOOKUPS];
+    out->bvh_node_visits = c[C_BVH_NODE_VISITS];
+    if (ctx->events_pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) == hipSuccess) out->kernel_ms = ms;
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_hue_table(int preset, float out_rgb[8][3]) {
+    static const float int_abs[8][3] = {{1, 0, 0}, {1, 1, 0}, {1, 1, 0}, {0, 1, 1}, {0, 1, 1}, {0, 1, 1}, {1, 0, 1}, {1, 0, 1}};
+    static const float float_abs[8][3] = {{1, 0, 0}, {1, 0.75f, 0}, {0.5f, 1, 0}, {0, 1, 0.25f}, {0, 1, 1}, {0, 0.25f, 1}, {0.5f, 0, 1}, {1, 0, 0.75f}};
+    if (out_rgb == nullptr || (preset != RT_HUE_INT_ABS && preset != RT_HUE_FLOAT_ABS)) return RT_ERR_INVALID_ARGUMENT;
+    std::memcpy(out_rgb, preset == RT_HUE_INT_ABS ? int_abs : float_abs, sizeof int_abs);
+    return RT_OK;
+}
+
+uint64_t rt_bands_pixel_count(uint32_t width, uint32_t height, const rt_bands* bands) {
+    if (bands == nullptr) return static_cast<uint64_t>(width) * height;
+    if (bands->band_rows == 0 || bands->band_stride == 0) return 0;
+    uint64_t rows = 0;
+    for (uint64_t band = bands->first_band;; band += bands->band_stride) {
+        const uint64_t y0 = band * bands->band_rows;
+        if (y0 >= height) break;
+        const uint64_t y1 = y0 + bands->band_rows;
+        rows += (y1 > height ? height : y1) - y0;
+    }
+    return rows * width;
+}
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int rt_create(rt_ctx** out_ctx, int device_id) {
+    if (out_ctx == nullptr) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "rt_create: out_ctx is NULL");
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device is visible (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= count) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "device %d out of range (0..%d)", device_id, count - 1);
+    rt_ctx* ctx = new rt_ctx;
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&prop, device_id) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, RT_ERR_HIP, "cannot select HIP device %d", device_id);
+    }
+    ctx->n_cus = prop.multiProcessorCount;
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->d_queue), 256) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), C_COUNT * sizeof(unsigned long long)) != hipSuccess ||
+        hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, RT_ERR_HIP, "cannot allocate context resources on device %d", device_id);
+    }
+    (void)hipMemset(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long));
+    *out_ctx = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx* ctx) {
+    if (ctx == nullptr) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    free_scene(ctx);
+    for (Buffer* b : {&ctx->samples, &ctx->stack, &ctx->out_staging, &ctx->photon_tables, &ctx->kat_a, &ctx->kat_b, &ctx->kat_c, &ctx->kat_d}) {
+        if (b->ptr) (void)hipFree(b->ptr);
+    }
+    if (ctx->d_point_lights) (void)hipFree(ctx->d_point_lights);
+    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    delete ctx;
+}
+
+int rt_set_option(rt_ctx* ctx, int option, int64_t value) {
+    if (ctx == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    switch (option) {
+        case RT_OPT_COLLECT_STATS: ctx->collect_stats = value != 0; return RT_OK;
+        case RT_OPT_BVH_MIN_TRIANGLES: ctx->bvh_min_triangles = value; return RT_OK;
+        case RT_OPT_DOF_SEED: ctx->dof_seed = static_cast<uint32_t>(value); return RT_OK;
+        default: return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
+    }
+}
+
+int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
+    if (ctx == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    if (d == nullptr) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_scene_upload: desc is NULL");
+    if (d->abi_version != RT_ABI_VERSION) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_scene_desc.abi_version %u != %u", d->abi_version, RT_ABI_VERSION);
+    const rt_camera& cam = d->camera;
+    if (cam.width == 0 || cam.height == 0 || cam.supersampling == 0) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "camera resolution and supersampling must be > 0");
+    if (cam.max_bounces > 64) return fail(ctx, RT_ERR_LIMIT, "max_bounces %u > 64", cam.max_bounces);
+    if (cam.supersampling > 64) return fail(ctx, RT_ERR_LIMIT, "supersampling %u > 64", cam.supersampling);
+    // validate every index before anything reaches a kernel
+    for (uint32_t i = 0; i < d->n_objects; i++) {
+        const rt_object& o = d->objects[i];
+        const uint32_t limit = o.kind == RT_OBJ_SPHERE ? d->n_spheres : o.kind == RT_OBJ_TRIANGLE ? d->n_triangles : o.kind == RT_OBJ_JULIA ? d->n_julias : 0;
+        if (o.index >= limit) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "object %u: kind %d index %u out of range", i, o.kind, o.index);
+        if (o.material >= d->n_materials) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "object %u: material %u out of range", i, o.material);
+    }
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        if (d->materials[i].texture >= static_cast<int32_t>(d->n_textures)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "material %u: texture %d out of range", i, d->materials[i].texture);
+    }
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const rt_texture& t = d->textures[i];
+        if (t.width == 0 || t.height == 0 || t.offset + static_cast<uint64_t>(t.width) * t.height * 4 > d->n_texel_bytes) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "texture %u lies outside the texel pool", i);
+    }
+    if (d->photon_steps > 0.0f && d->photon_texture_size == 0) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "photon_texture_size must be > 0 when photon_steps > 0");
+
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RT_HIP_TRY(ctx, hipDeviceSynchronize());
+    free_scene(ctx);
+    DevScene& sc = ctx->dev;
+    std::memset(&sc, 0, sizeof sc);
+
+    // ---- camera frame (src/raytracer.cpp:17-29), evaluated in binary32 on the host ------------------
+    std::memcpy(sc.cam, cam.camera_to_world.m, sizeof sc.cam);
+    const float wf = static_cast<float>(cam.width), hf = static_cast<float>(cam.height);
+    const float half_x = -tanf(cam.fov), half_y = tanf(cam.fov) * (hf / wf);
+    sc.pixel_size[0] = (-2.0f / wf) * half_x;
+    sc.pixel_size[1] = (-2.0f / hf) * half_y;
+    std::vector<float> ray_x(cam.width), ray_y(cam.height), sub_disp(cam.supersampling);
+    {
+        float rx = half_x + 0.5f * sc.pixel_size[0];
+        for (uint32_t x = 0; x < cam.width; x++) {
+            ray_x[x] = rx;
+            rx += sc.pixel_size[0];
+        }
+        for (uint32_t y = 0; y < cam.height; y++) ray_y[y] = half_y + y * sc.pixel_size[1] + 0.5f * sc.pixel_size[1];
+        for (uint32_t i = 0; i < cam.supersampling; i++) sub_disp[i] = 2.0f * (i + 1) / (cam.supersampling + 1) - 1.0f;
+    }
+    int rc;
+    if ((rc = upload(ctx, ray_x, &sc.ray_x)) != RT_OK) return rc;
+    if ((rc = upload(ctx, ray_y, &sc.ray_y)) != RT_OK) return rc;
+    if ((rc = upload(ctx, sub_disp, &sc.sub_disp)) != RT_OK) return rc;
+    sc.focus_distance = cam.focus_distance;
+    sc.lens_size = cam.lens_size;
+    sc.width = cam.width;
+    sc.height = cam.height;
+    sc.supersampling = cam.supersampling;
+    sc.max_bounces = cam.max_bounces;
+    sc.inv_samples = 1.0f / (cam.supersampling * cam.supersampling);
+    sc.dispersion = d->dispersion_mode ? 1 : 0;
+    for (int h = 0; h < 8; h++) {
+        for (int c = 0; c < 3; c++) sc.hue[h][c] = d->hue_rgb[h][c];
+        sc.hue[h][3] = 1.0f;
+    }
+    std::memcpy(sc.background, d->background, sizeof sc.background);
+    std::memcpy(sc.ambient, d->ambient, sizeof sc.ambient);
+
+    // ---- lights ------------------------------------------------------------------------------------
+    std::vector<DevLight> lights(d->n_lights);
+    ctx->point_lights.clear();
+    for (uint32_t i = 0; i < d->n_lights; i++) {
+        std::memcpy(lights[i].position, d->lights[i].position, sizeof lights[i].position);
+        lights[i].type = d->lights[i].type == RT_LIGHT_PARALLEL ? 0 : 1;
+        std::memcpy(lights[i].power, d->lights[i].power, sizeof lights[i].power);
+        if (lights[i].type == 1) ctx->point_lights.push_back(i);
+    }
+    sc.n_lights = d->n_lights;
+    if ((rc = upload(ctx, lights, &sc.lights)) != RT_OK) return rc;
+
+    // ---- materials, textures -----------------------------------------------------------------------
+    std::vector<DevMaterial> mats(d->n_materials);
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const rt_material& m = d->materials[i];
+        DevMaterial& o = mats[i];
+        std::memcpy(o.color, m.color, sizeof o.color);
+        o.texture = m.texture;
+        o.ka = m.ka; o.kd = m.kd; o.ks = m.ks; o.exponent = m.exponent;
+        o.reflectance = m.reflectance; o.transmittance = m.transmittance;
+        o.refr_re = m.refraction_re; o.refr_im = m.refraction_im; o.dispersion = m.dispersion;
+        o.refr_norm = m.refraction_re * m.refraction_re + m.refraction_im * m.refraction_im;   // std::norm
+        o.pad = 0.0f;
+    }
+    if ((rc = upload(ctx, mats, &sc.materials)) != RT_OK) return rc;
+    std::vector<DevTexture> texs(d->n_textures);
+    std::vector<float4> texels;
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const rt_texture& t = d->textures[i];
+        texs[i] = {t.width, t.height, static_cast<uint32_t>(texels.size()), 0u};
+        const uint8_t* src = d->texels + t.offset;
+        const size_t n = static_cast<size_t>(t.width) * t.height;
+        for (size_t k = 0; k < n; k++) {
+            // Color(UColor): u8 / 255.0f per channel (src/types.h:272)
+            texels.push_back(make_float4(src[k * 4 + 0] / 255.0f, src[k * 4 + 1] / 255.0f, src[k * 4 + 2] / 255.0f, src[k * 4 + 3] / 255.0f));
+        }
+    }
+    if (texels.size() > 0xffffffffull) return fail(ctx, RT_ERR_LIMIT, "texture pool too large");
+    if ((rc = upload(ctx, texs, &sc.textures)) != RT_OK) return rc;
+    if ((rc = upload(ctx, texels, &sc.texels)) != RT_OK) return rc;
+
+    // ---- geometry ----------------------------------------------------------------------------------
+    std::vector<DevSphere> spheres(d->n_spheres);
+    for (uint32_t i = 0; i < d->n_spheres; i++) {
+        const rt_sphere& s = d->spheres[i];
+        std::memcpy(spheres[i].center, s.center, sizeof s.center);
+        spheres[i].radius = s.radius;
+        std::memcpy(spheres[i].w2o, s.world_to_object.m, sizeof spheres[i].w2o);
+        std::memcpy(spheres[i].o2w, s.object_to_world.m, sizeof spheres[i].o2w);
+        std::memcpy(spheres[i].o2wn, s.object_to_world_normals.m, sizeof spheres[i].o2wn);
+    }
+    std::vector<DevTriTest> tt(d->n_triangles);
+    std::vector<DevTriShade> ts(d->n_triangles);
+    for (uint32_t i = 0; i < d->n_triangles; i++) {
+        const rt_triangle& t = d->triangles[i];
+        for (int c = 0; c < 3; c++) {
+            tt[i].p0[c] = t.position[0][c];
+            tt[i].e1[c] = t.position[1][c] - t.position[0][c];   // edge1, src/objects.cpp:56
+            tt[i].e2[c] = t.position[2][c] - t.position[0][c];   // edge2, src/objects.cpp:57
+            tt[i].pad[c] = 0.0f;
+            ts[i].n0[c] = t.normal[0][c];
+            ts[i].n1[c] = t.normal[1][c];
+            ts[i].n2[c] = t.normal[2][c];
+        }
+        for (int c = 0; c < 2; c++) {
+            ts[i].uv0[c] = t.uv[0][c];
+            ts[i].uv1[c] = t.uv[1][c];
+            ts[i].uv2[c] = t.uv[2][c];
+        }
+        ts[i].pad = 0.0f;
+    }
+    // per-object tables, runs (Julia objects are kept out of the uniform loop) and photon slots
+    std::vector<uint32_t> obj_material(d->n_objects);
+    ctx->photon_slot.assign(d->n_objects, -1);
+    ctx->object_kind.assign(d->n_objects, 0);
+    ctx->object_prim.assign(d->n_objects, 0);
+    std::vector<DevRun> runs;
+    std::vector<DevJulia> julias;
+    ctx->n_slots = 0;
+    // geometry tables are re-ordered into scene order so that a run is contiguous
+    std::vector<DevSphere> spheres_ord;
+    std::vector<DevTriTest> tt_ord;
+    std::vector<DevTriShade> ts_ord;
+    for (uint32_t i = 0; i < d->n_objects; i++) {
+        const rt_object& o = d->objects[i];
+        obj_material[i] = o.material;
+        ctx->object_kind[i] = static_cast<uint32_t>(o.kind);
+        const DevMaterial& m = mats[o.material];
+        if (d->photon_steps > 0.0f && m.refr_norm <= 0.0f) ctx->photon_slot[i] = static_cast<int32_t>(ctx->n_slots++);
+        if (o.kind == RT_OBJ_JULIA) {
+            const rt_julia& j = d->julias[o.index];
+            DevJulia dj{};
+            std::memcpy(dj.position, j.position, sizeof dj.position);
+            dj.scale = j.scale;
+            std::memcpy(dj.c, j.c, sizeof dj.c);
+            dj.cut_plane = j.cut_plane;
+            dj.inv_scale = 1.0f / j.scale;
+            dj.object = i;
+            dj.material = o.material;
+            std::memcpy(dj.w2o, j.world_to_object.m, sizeof dj.w2o);
+            std::memcpy(dj.o2w, j.object_to_world.m, sizeof dj.o2w);
+            std::memcpy(dj.o2wn, j.object_to_world_normals.m, sizeof dj.o2wn);
+            ctx->object_prim[i] = static_cast<uint32_t>(julias.size());
+            julias.push_back(dj);
+            continue;
+        }
+        const int kind = o.kind == RT_OBJ_SPHERE ? RUN_SPHERES : RUN_TRIANGLES;
+        uint32_t prim;
+        if (kind == RUN_SPHERES) {
+            prim = static_cast<uint32_t>(spheres_ord.size());
+            spheres_ord.push_back(spheres[o.index]);
+        } else {
+            prim = static_cast<uint32_t>(tt_ord.size());
+            tt_ord.push_back(tt[o.index]);
+            ts_ord.push_back(ts[o.index]);
+        }
+        ctx->object_prim[i] = prim;
+        if (!runs.empty() && runs.back().kind == kind && runs.back().first_object + runs.back().count == i) {
+            runs.back().count++;
+        } else {
+            DevRun r{};
+            r.kind = kind;
+            r.first_object = i;
+            r.first_prim = prim;
+            r.count = 1;
+            runs.push_back(r);
+        }
+    }
+    sc.n_objects = d->n_objects;
+    sc.n_runs = static_cast<uint32_t>(runs.size());
+    sc.n_julias = static_cast<uint32_t>(julias.size());
+    if ((rc = upload(ctx, runs, &sc.runs)) != RT_OK) return rc;
+    if ((rc = upload(ctx, tt_ord, &sc.tri_test)) != RT_OK) return rc;
+    if ((rc = upload(ctx, ts_ord, &sc.tri_shade)) != RT_OK) return rc;
+    if ((rc = upload(ctx, spheres_ord, &sc.spheres)) != RT_OK) return rc;
+    if ((rc = upload(ctx, julias, &sc.julias)) != RT_OK) return rc;
+    if ((rc = upload(ctx, obj_material, &sc.object_material)) != RT_OK) return rc;
+    if ((rc = upload(ctx, ctx->photon_slot, &sc.object_photon_slot)) != RT_OK) return rc;
+    sc.bvh_nodes = nullptr;
+    sc.bvh_prims = nullptr;
+
+    // ---- photon atlas and scan tables (src/photonmap.cpp:38-45) ----------------------------------------
+    ctx->photon_steps = d->photon_steps;
+    ctx->hues = sc.dispersion ? 8u : 1u;
+    sc.photon_size = d->photon_texture_size;
+    sc.photon_factor = d->photon_factor;
+    sc.photon_atlas = nullptr;
+    ctx->n_phi = ctx->n_theta = 0;
+    if (d->photon_steps > 0.0f && ctx->n_slots > 0) {
+        const size_t atlas_bytes = static_cast<size_t>(ctx->n_slots) * sc.photon_size * sc.photon_size * sizeof(float4);
+        void* atlas = nullptr;
+        RT_HIP_TRY(ctx, hipMalloc(&atlas, atlas_bytes));
+        ctx->scene_allocs.push_back(atlas);
+        RT_HIP_TRY(ctx, hipMemset(atlas, 0, atlas_bytes));
+        sc.photon_atlas = static_cast<float4*>(atlas);
+    }
+    if (d->photon_steps > 0.0f) {
+        // the scan angles are accumulated in float by the reference's loops; reproduce them exactly
+        const float step = 2 * 3.14159265358979323846f / d->photon_steps;
+        std::vector<float> sp, cp, st, ct;
+        if (!(step > 0.0f)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "photon_steps gives a non-positive scan step");
+        for (float phi = 0.0f; phi < 2 * 3.14159265358979323846f; phi += step) {
+            sp.push_back(sinf(phi));
+            cp.push_back(cosf(phi));
+            if (sp.size() > (1u << 24)) return fail(ctx, RT_ERR_LIMIT, "photon_steps too large");
+        }
+        for (float theta = 0.0f; theta < 3.14159265358979323846f; theta += step) {
+            st.push_back(sinf(theta));
+            ct.push_back(cosf(theta));
+        }
+        ctx->n_phi = static_cast<uint32_t>(sp.size());
+        ctx->n_theta = static_cast<uint32_t>(st.size());
+        std::vector<float> all;
+        all.insert(all.end(), sp.begin(), sp.end());
+        all.insert(all.end(), cp.begin(), cp.end());
+        all.insert(all.end(), st.begin(), st.end());
+        all.insert(all.end(), ct.begin(), ct.end());
+        if ((rc = grow(ctx, ctx->photon_tables, all.size() * sizeof(float))) != RT_OK) return rc;
+        RT_HIP_TRY(ctx, hipMemcpy(ctx->photon_tables.ptr, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (ctx->d_point_lights) (void)hipFree(ctx->d_point_lights);
+        ctx->d_point_lights = nullptr;
+        RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_point_lights), (ctx->point_lights.size() + 1) * sizeof(uint32_t)));
+        if (!ctx->point_lights.empty()) RT_HIP_TRY(ctx, hipMemcpy(ctx->d_point_lights, ctx->point_lights.data(), ctx->point_lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    ctx->n_objects = d->n_objects;
+    ctx->has_scene = true;
+    return RT_OK;
+}
+
+int rt_photon_generate_device(rt_ctx* ctx, void* hip_stream) {
+    if (ctx == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return photon_enqueue(ctx, static_cast<hipStream_t>(hip_stream));
+}
+
+int rt_photon_generate(rt_ctx* ctx, rt_stats* stats) {
+    const int rc = rt_photon_generate_device(ctx, nullptr);
+    if (rc != RT_OK) return rc;
+    RT_HIP_TRY(ctx, hipStreamSynchronize(nullptr));
+    return read_stats(ctx, stats);
+}
+
+int rt_render_device(rt_ctx* ctx, const rt_bands* bands, void* d_rgba_out, void* hip_stream) {
+    if (ctx == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    if (d_rgba_out == nullptr) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render_device: output pointer is NULL");
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return render_enqueue(ctx, bands, static_cast<float4*>(d_rgba_out), static_cast<hipStream_t>(hip_stream));
+}
+
+int rt_render(rt_ctx* ctx, const rt_bands* bands, float* rgba_out, rt_stats* stats) {
+    if (ctx == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    if (rgba_out == nullptr) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render: output pointer is NULL");
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_render before rt_scene_upload");
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_pixels = rt_bands_pixel_count(ctx->dev.width, ctx->dev.height, bands);
+    if (n_pixels == 0) return read_stats(ctx, stats);
+    int rc = grow(ctx, ctx->out_staging, n_pixels * sizeof(float4));
+    if (rc != RT_OK) return rc;
+    rc = render_enqueue(ctx, bands, static_cast<float4*>(ctx->out_staging.ptr), nullptr);
+    if (rc != RT_OK) return rc;
+    RT_HIP_TRY(ctx, hipMemcpy(rgba_out, ctx->out_staging.ptr, n_pixels * sizeof(float4), hipMemcpyDeviceToHost));
+    return read_stats(ctx, stats);
+}
+
+int rt_fetch_stats(rt_ctx* ctx, rt_stats* out) {
+    if (ctx == nullptr || out == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return read_stats(ctx, out);
+}
+
+int rt_photon_download(rt_ctx* ctx, uint32_t object_index, float* rgba_out) {
+    if (ctx == nullptr || rgba_out == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_photon_download before rt_scene_upload");
+    if (object_index >= ctx->n_objects) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "object index %u out of range", object_index);
+    const size_t n = static_cast<size_t>(ctx->dev.photon_size) * ctx->dev.photon_size;
+    const int32_t slot = ctx->photon_slot[object_index];
+    if (slot < 0 || ctx->dev.photon_atlas == nullptr) {
+        std::memset(rgba_out, 0, n * sizeof(float4));
+        return RT_OK;
+    }
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RT_HIP_TRY(ctx, hipMemcpy(rgba_out, ctx->dev.photon_atlas + n * slot, n * sizeof(float4), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_mul_add_device(rt_ctx* ctx, void* d_acc, const void* d_src, float factor, uint64_t n_floats, void* hip_stream) {
+    if (ctx == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    if (n_floats == 0) return RT_OK;
+    if (d_acc == nullptr || d_src == nullptr) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_mul_add_device: NULL buffer");
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const unsigned g = static_cast<unsigned>((n_floats + 255) / 256);
+    hipLaunchKernelGGL(mul_add_kernel, dim3(g), dim3(256), 0, static_cast<hipStream_t>(hip_stream), static_cast<float*>(d_acc), static_cast<const float*>(d_src), factor, n_floats);
+    RT_HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_quantize_device(rt_ctx* ctx, const void* d_rgba, void* d_rgba8, float gain, uint64_t n_pixels, void* hip_stream) {
+    if (ctx == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    if (n_pixels == 0) return RT_OK;
+    if (d_rgba == nullptr || d_rgba8 == nullptr) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_quantize_device: NULL buffer");
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const unsigned g = static_cast<unsigned>((n_pixels + 255) / 256);
+    hipLaunchKernelGGL(quantize_kernel, dim3(g), dim3(256), 0, static_cast<hipStream_t>(hip_stream), static_cast<const float4*>(d_rgba), static_cast<uchar4*>(d_rgba8), gain, n_pixels);
+    RT_HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+// ---- known-answer hooks (tests only; declared in include/rt_hip.h under "test hooks") ----------------
+
+// Object::intersect (reference src/objects.h:124-126) of scene object object_index[i] for n rays given
+// as 7 floats each (origin, direction as passed to the Ray constructor, max_distance);
+// out = 12 floats per ray: hit flag, distance, point, normal, uv, photon uv.
+int rt_kat_intersect(rt_ctx* ctx, const uint32_t* object_index, const float* rays, uint32_t n, float* out) {
+    if (ctx == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_kat_intersect before rt_scene_upload");
+    if (n == 0) return RT_OK;
+    if (object_index == nullptr || rays == nullptr || out == nullptr) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_kat_intersect: NULL buffer");
+    std::vector<uint32_t> kind(n), prim(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (object_index[i] >= ctx->n_objects) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "ray %u: object %u out of range", i, object_index[i]);
+        kind[i] = ctx->object_kind[object_index[i]];
+        prim[i] = ctx->object_prim[object_index[i]];
+    }
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = grow(ctx, ctx->kat_a, n * sizeof(uint32_t))) != RT_OK) return rc;
+    if ((rc = grow(ctx, ctx->kat_b, n * sizeof(uint32_t))) != RT_OK) return rc;
+    if ((rc = grow(ctx, ctx->kat_c, static_cast<size_t>(n) * 7 * sizeof(float))) != RT_OK) return rc;
+    if ((rc = grow(ctx, ctx->kat_d, static_cast<size_t>(n) * 12 * sizeof(float))) != RT_OK) return rc;
+    RT_HIP_TRY(ctx, hipMemcpy(ctx->kat_a.ptr, kind.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    RT_HIP_TRY(ctx, hipMemcpy(ctx->kat_b.ptr, prim.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    RT_HIP_TRY(ctx, hipMemcpy(ctx->kat_c.ptr, rays, static_cast<size_t>(n) * 7 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kat_intersect_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, ctx->dev, static_cast<const unsigned*>(ctx->kat_a.ptr),
+                       static_cast<const unsigned*>(ctx->kat_b.ptr), static_cast<const float*>(ctx->kat_c.ptr), n, static_cast<float*>(ctx->kat_d.ptr));
+    RT_HIP_TRY(ctx, hipGetLastError());
+    RT_HIP_TRY(ctx, hipMemcpy(out, ctx->kat_d.ptr, static_cast<size_t>(n) * 12 * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// calcFresnel (reference src/raytracer.cpp:243-268) for n records of 5 floats
+// (refraction re, im, dispersion, cos, wavelength); out = kr per record.
+int rt_kat_fresnel(rt_ctx* ctx, const float* records, uint32_t n, float* out) {
+    if (ctx == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    if (n == 0) return RT_OK;
+    if (records == nullptr || out == nullptr) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_kat_fresnel: NULL buffer");
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = grow(ctx, ctx->kat_c, static_cast<size_t>(n) * 5 * sizeof(float))) != RT_OK) return rc;
+    if ((rc = grow(ctx, ctx->kat_d, static_cast<size_t>(n) * sizeof(float))) != RT_OK) return rc;
+    RT_HIP_TRY(ctx, hipMemcpy(ctx->kat_c.ptr, records, static_cast<size_t>(n) * 5 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kat_fresnel_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, static_cast<const float*>(ctx->kat_c.ptr), n, static_cast<float*>(ctx->kat_d.ptr));
+    RT_HIP_TRY(ctx, hipGetLastError());
+    RT_HIP_TRY(ctx, hipMemcpy(out, ctx->kat_d.ptr, static_cast<size_t>(n) * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,268 @@
+// Device intersectors and shading helpers (gfx950).  Each function names the reference lines whose
+// arithmetic it reproduces; see rt_device_math.h for the arithmetic contract.
+#pragma once
+
+#include "rt_device_math.h"
+#include "rt_scene_dev.h"
+
+namespace rtd {
+
+struct HitRec {
+    float dist;
+    V3 point, normal;
+    V2 uv, ph;
+};
+
+// ---- Möller–Trumbore without determinant epsilon or culling (src/objects.cpp:52-81) -------------
+// Returns true with (u, v, t) when the reference would go on to build an Intersection.
+RT_DEV bool tri_test(const DevTriTest& t, V3 o, V3 d, float maxd, float& u, float& v, float& dist) {
+    const V3 e1 = v3(t.e1[0], t.e1[1], t.e1[2]);
+    const V3 e2 = v3(t.e2[0], t.e2[1], t.e2[2]);
+    const V3 h = cross(d, e2);
+    const float a = dot(e1, h);
+    const V3 s = o - v3(t.p0[0], t.p0[1], t.p0[2]);
+    u = dot(s, h) / a;
+    if (u < -kEpsilon || u > 1.0f) return false;
+    const V3 q = cross(s, e1);
+    v = dot(d, q) / a;
+    if (v < -kEpsilon || u + v > 1.0f) return false;
+    dist = dot(e2, q) / a;
+    if (dist < 0 || dist > maxd) return false;
+    return true;
+}
+
+// Rest of Triangle::intersect (src/objects.cpp:83-98)
+RT_DEV void tri_finish(const DevTriShade& s, V3 o, V3 d, float u, float v, float dist, HitRec& h) {
+    const float w = 1.0f - (u + v);
+    h.dist = dist;
+    h.point = o + d * dist;
+    h.normal = normalized(v3(s.n0[0], s.n0[1], s.n0[2]) * w + v3(s.n1[0], s.n1[1], s.n1[2]) * u +
+                          v3(s.n2[0], s.n2[1], s.n2[2]) * v);
+    h.uv = {s.uv0[0] * w + s.uv1[0] * u + s.uv2[0] * v, s.uv0[1] * w + s.uv1[1] * u + s.uv2[1] * v};
+    h.ph = {w, u};
+}
+
+// ---- Sphere::intersect (src/objects.cpp:9-50) --------------------------------------------------
+RT_DEV bool sphere_intersect(const DevSphere& s, V3 o_w, V3 d_w, float maxd, HitRec& h) {
+    const V3 o = xform_point(s.w2o, o_w);
+    const V3 d = normalized(xform_dir(s.w2o, d_w));
+    float object_max = kInfinite;
+    if (maxd != kInfinite) object_max = length(o - xform_point(s.w2o, o_w + d_w * maxd));
+    const V3 center = v3(s.center[0], s.center[1], s.center[2]);
+    const V3 vc = o - center;
+    const float b = dot(vc, d);
+    const float c = dot(vc, vc) - s.radius * s.radius;
+    const float disc = b * b - c;
+    if (disc < 0.0f) return false;
+    float t = root_minus(b, disc);
+    if (t > object_max) return false;
+    if (t < 0) {
+        t = root_plus(b, disc);
+        if (t < 0 || t > object_max) return false;
+    }
+    const V3 p = o + d * t;
+    const V3 n = normalized(p - center);
+    const V2 uv = {0.5f + atan2f(n.x, n.z) / (2.0f * kPi), 0.5f - asinf(n.y) / kPi};
+    const V3 pw = xform_point(s.o2w, p);
+    h.dist = length(o_w - pw);
+    h.point = pw;
+    h.normal = normalized(xform_point(s.o2wn, n));
+    h.uv = uv;
+    h.ph = uv;
+    return true;
+}
+
+// ---- Julia (src/objects.cpp:101-242) -----------------------------------------------------------
+constexpr unsigned kJuliaSearchIterations = 10240;
+constexpr float kJuliaConvergence = 0.0001f;
+constexpr float kJuliaDivergence = 10000.0f;
+constexpr unsigned kJuliaDistanceIterations = 10000;
+constexpr float kJuliaGradientDiff = 0.005f;
+constexpr unsigned kJuliaGradientIterations = 8;
+
+struct Quat {
+    float r, a, b, c;
+};
+
+// Julia::estimateDistance (src/objects.cpp:122-135).  The Hamilton square is written term for term
+// as src/types.h:246-253 evaluates z*z.  Exact early-out: once d2 is +inf and m2 stays finite the
+// returned value is (+/-)0 whatever the remaining iterations do.
+template <bool COUNT>
+RT_DEV float julia_distance(Quat z, Quat c, unsigned iterations, unsigned long long& n_iter) {
+    float d2 = 1.0f;
+    float m2 = z.r * z.r + z.a * z.a + z.b * z.b + z.c * z.c;
+    for (unsigned i = 0; i < iterations; i++) {
+        if (COUNT) n_iter++;
+        d2 *= 4.0f * m2;
+        const float nr = z.r * z.r - z.a * z.a - z.b * z.b - z.c * z.c;
+        const float na = z.r * z.a + z.a * z.r + z.b * z.c - z.c * z.b;
+        const float nb = z.r * z.b - z.a * z.c + z.b * z.r + z.c * z.a;
+        const float nc = z.r * z.c + z.a * z.b - z.b * z.a + z.c * z.r;
+        z = {nr + c.r, na + c.a, nb + c.b, nc + c.c};
+        m2 = z.r * z.r + z.a * z.a + z.b * z.b + z.c * z.c;
+        if (m2 > 1e10f) break;
+        if (d2 == __builtin_inff()) break;
+    }
+    // sqrt(m2/d2)*0.5f*log(sqrt(m2)): float division, everything else in double (Y8)
+    const double tail = sqrt(static_cast<double>(m2 / d2)) * 0.5 * log(sqrt(static_cast<double>(m2)));
+    return static_cast<float>(tail);
+}
+
+// Julia::estimateNormal (src/objects.cpp:140-160), object space
+template <bool COUNT>
+RT_DEV V3 julia_normal(V3 p, float cut, Quat c, unsigned long long& n_iter) {
+    const float e = kJuliaGradientDiff;
+    const float d0 = julia_distance<COUNT>({p.x + e, p.y + 0.0f, p.z + 0.0f, cut + 0.0f}, c, kJuliaGradientIterations, n_iter);
+    const float d1 = julia_distance<COUNT>({p.x + -e, p.y + 0.0f, p.z + 0.0f, cut + 0.0f}, c, kJuliaGradientIterations, n_iter);
+    const float d2 = julia_distance<COUNT>({p.x + 0.0f, p.y + e, p.z + 0.0f, cut + 0.0f}, c, kJuliaGradientIterations, n_iter);
+    const float d3 = julia_distance<COUNT>({p.x + 0.0f, p.y + -e, p.z + 0.0f, cut + 0.0f}, c, kJuliaGradientIterations, n_iter);
+    const float d4 = julia_distance<COUNT>({p.x + 0.0f, p.y + 0.0f, p.z + e, cut + 0.0f}, c, kJuliaGradientIterations, n_iter);
+    const float d5 = julia_distance<COUNT>({p.x + 0.0f, p.y + 0.0f, p.z + -e, cut + 0.0f}, c, kJuliaGradientIterations, n_iter);
+    return normalized(v3(d0 - d1, d2 - d3, d4 - d5));
+}
+
+// First part of Julia::intersect (src/objects.cpp:164-198): ray to object space and the jump to the
+// bounding sphere.  Returns false on a miss of the bounding sphere.
+RT_DEV bool julia_enter(const DevJulia& j, V3 o_w, V3 d_w, V3& p, V3& d) {
+    p = (xform_point(j.w2o, o_w) - v3(j.position[0], j.position[1], j.position[2])) * j.inv_scale;
+    d = normalized(xform_dir(j.w2o, d_w));
+    const float bound = sqrtf(3.0f);
+    if (length(p) > bound) {
+        const float b = dot(p, d);
+        const float c = dot(p, p) - bound * bound;
+        const float disc = b * b - c;
+        if (disc <= 0.0f) return false;
+        const float t = root_minus(b, disc);
+        if (t < 0) return false;
+        p = p + d * t;
+    }
+    return true;
+}
+
+// Last part of Julia::intersect (src/objects.cpp:223-241) for a converged march position p.
+template <bool COUNT>
+RT_DEV bool julia_finish(const DevJulia& j, V3 o_w, V3 p, V3 d, float maxd, HitRec& h, unsigned long long& n_iter) {
+    V3 n = julia_normal<COUNT>(p, j.cut_plane, {j.c[0], j.c[1], j.c[2], j.c[3]}, n_iter);
+    if (dot(n, d) > 0.0f) n = n * -1.0f;
+    const V3 pw = xform_point(j.o2w, p * j.scale + v3(j.position[0], j.position[1], j.position[2]));
+    const float dist = length(pw - o_w);
+    if (dist < kEpsilon || dist > maxd) return false;
+    h.dist = dist;
+    h.point = pw;
+    h.normal = normalized(xform_point(j.o2wn, n));
+    h.uv = {0.0f, 0.0f};
+    h.ph = {0.0f, 0.0f};
+    return true;
+}
+
+// One march step (src/objects.cpp:206-217).  Returns 0 = keep marching, 1 = converged (hit
+// candidate), 2 = gave up (miss).  `i` is the step index before the call.
+template <bool COUNT>
+RT_DEV int julia_step(const DevJulia& j, V3& p, V3 d, unsigned& i, unsigned long long& n_iter) {
+    float dist = julia_distance<COUNT>({p.x, p.y, p.z, j.cut_plane}, {j.c[0], j.c[1], j.c[2], j.c[3]}, kJuliaDistanceIterations, n_iter);
+    if (i == 0 && dist < kJuliaConvergence) {
+        dist = 100 * kJuliaConvergence;
+    } else if (dist < kJuliaConvergence || dist > kJuliaDivergence) {
+        return dist >= kJuliaConvergence ? 2 : 1;
+    }
+    p = p + d * dist;
+    i++;
+    if (i >= kJuliaSearchIterations) return dist >= kJuliaConvergence ? 2 : 1;
+    return 0;
+}
+
+// Whole Julia::intersect in one go (used where no wave-level scheduling is worth it: the
+// known-answer kernel and the photon pass).
+template <bool COUNT>
+RT_DEV bool julia_intersect_inline(const DevJulia& j, V3 o_w, V3 d_w, float maxd, HitRec& h,
+                                   unsigned long long& n_steps, unsigned long long& n_iter) {
+    V3 p, d;
+    if (!julia_enter(j, o_w, d_w, p, d)) return false;
+    unsigned i = 0;
+    int r;
+    do {
+        if (COUNT) n_steps++;
+        r = julia_step<COUNT>(j, p, d, i, n_iter);
+    } while (r == 0);
+    if (r == 2) return false;
+    return julia_finish<COUNT>(j, o_w, p, d, maxd, h, n_iter);
+}
+
+// ---- texture (src/raytracer.cpp:166-199) -------------------------------------------------------
+RT_DEV Col texture_bilinear(const DevTexture& tex, const float4* __restrict__ texels, V2 uv) {
+    const unsigned w = tex.width, hgt = tex.height;
+    uv.x = frac_part(uv.x);
+    uv.y = frac_part(uv.y);
+    const float px = uv.x * static_cast<float>(w - 1), py = uv.y * static_cast<float>(hgt - 1);
+    const unsigned x0 = clamp_u32(cast_u32(px), 0u, w - 1), y0 = clamp_u32(cast_u32(py), 0u, hgt - 1);
+    const unsigned x1 = clamp_u32(cast_u32(ceilf(px)), 0u, w - 1), y1 = clamp_u32(cast_u32(ceilf(py)), 0u, hgt - 1);
+    const float fx = frac_part(px), fy = frac_part(py);
+    const float f1 = (1 - fx) * (1 - fy), f2 = fx * (1 - fy), f3 = (1 - fx) * fy, f4 = fx * fy;
+    const float4* base = texels + tex.first_texel;
+    const float4 t1 = base[static_cast<size_t>(y0) * w + x0], t2 = base[static_cast<size_t>(y0) * w + x1];
+    const float4 t3 = base[static_cast<size_t>(y1) * w + x0], t4 = base[static_cast<size_t>(y1) * w + x1];
+    const Col c1 = {t1.x, t1.y, t1.z, t1.w}, c2 = {t2.x, t2.y, t2.z, t2.w}, c3 = {t3.x, t3.y, t3.z, t3.w}, c4 = {t4.x, t4.y, t4.z, t4.w};
+    return c1 * f1 + c2 * f2 + c3 * f3 + c4 * f4;
+}
+
+// ---- Fresnel (src/raytracer.cpp:243-268, again at src/photonmap.cpp:92-116) ---------------------
+RT_DEV float fresnel_kr(float refr_re, float refr_im, float dispersion, float cos_rn, float wavelength) {
+    Cx etai = {1.0f, 0.0f};
+    Cx etat = {refr_re + wavelength * dispersion, refr_im};
+    if (cos_rn > 0.0f) {
+        const Cx t = etai;
+        etai = etat;
+        etat = t;
+    }
+    const float one_minus = 1 - cos_rn * cos_rn;
+    const float sin_i = sqrtf(0.0f < one_minus ? one_minus : 0.0f);   // std::max(0.0f, x)
+    const Cx sint = cx_scale(cx_div(etai, etat), sin_i);
+    if (cx_norm(sint) < 1.0f) {
+        const Cx ss = cx_mul(sint, sint);
+        const Cx cost = cx_sqrt({-ss.re + 1.0f, -ss.im});   // operator-(T, complex): -y then += x
+        const float ca = fabsf(cos_rn);
+        const Cx tc = cx_scale(etat, ca), ic = cx_scale(etai, ca);
+        const Cx i_cost = cx_mul(etai, cost), t_cost = cx_mul(etat, cost);
+        const Cx rs = cx_div(cx_sub(tc, i_cost), cx_add(tc, i_cost));
+        const Cx rp = cx_div(cx_sub(ic, t_cost), cx_add(ic, t_cost));
+        return (cx_norm(rs) + cx_norm(rp)) / 2;
+    }
+    return 1.0f;
+}
+
+// ---- refraction / reflection rays (src/raytracer.cpp:270-308) ----------------------------------
+RT_DEV bool refraction_ray(V3 dir, V3 point, V3 normal, float refr_re, float dispersion, float cos_rn,
+                           float wavelength, V3& o, V3& d) {
+    float cos_t = cos_rn;
+    V3 nt = normal;
+    float index = refr_re + wavelength * dispersion;
+    bool outside = false;
+    if (cos_rn <= 0.0f) {
+        outside = true;
+        cos_t *= -1.0f;
+        index = 1.0f / index;
+    } else {
+        nt = nt * -1.0f;
+    }
+    const float k = 1.0f - index * index * (1.0f - cos_t * cos_t);
+    if (!(k >= 0)) return false;
+    d = normalized(dir * index + nt * (index * cos_t - sqrtf(k)));
+    o = point + normal * (outside ? -kEpsilon : kEpsilon);
+    return true;
+}
+
+RT_DEV void reflection_ray(V3 dir, V3 point, V3 normal, float cos_rn, V3& o, V3& d) {
+    const bool outside = cos_rn <= 0.0f;
+    d = normalized(dir - normal * cos_rn * 2.0f);
+    o = point + normal * (outside ? kEpsilon : -kEpsilon);
+}
+
+// Texel of a photon texture (src/objects.cpp:249-252, 262-265)
+RT_DEV unsigned photon_texel(V2 pos, unsigned size) {
+    const float s1 = static_cast<float>(size - 1);
+    const unsigned x = clamp_u32(cast_u32(pos.x * s1), 0u, size - 1);
+    const unsigned y = clamp_u32(cast_u32(pos.y * s1), 0u, size - 1);
+    return y * size + x;
+}
+
+}  // namespace rtd

@@ -1,0 +1,736 @@
+// rt_kernels.hip — the trace path as CDNA4 (gfx950) kernels.
+//
+// Replaces (reference = clemy/RayTracer, /root/reference):
+//   RayTracer::Instance::Thread::raytraceLine / castRay / calcPhong / calcFresnel / calcRefraction /
+//   calcReflection                                   src/raytracer.cpp:55-308
+//   PhotonMapper::generate / castRay                 src/photonmap.cpp:20-146
+//
+// Execution model (not a translation of the reference's recursion):
+//   * one lane = one primary sample (pixel, sub-pixel, hue) at a time; lanes pull samples from a
+//     global queue in 8x8-pixel tiles, so a wave starts coherent and is refilled as lanes finish
+//     (persistent waves: divergence is cut by refill instead of by leaving lanes idle);
+//   * the recursion is a per-lane post-order DFS with an explicit frame stack in HBM
+//     ([frame][field][lane], coalesced), so child radiance is combined in the reference's order;
+//   * the expensive operation — one ray against every scene object — is a single wave-uniform
+//     object loop shared by nearest-hit, shadow and photon queries: geometry records are read with
+//     scalar loads into SGPRs, every lane with a pending query of any kind takes part;
+//   * Julia sets are marched outside that loop, one distance-estimator call per scheduling step,
+//     and a wave-level scheduler always runs the phase (query / march / normal / resolve) that the
+//     most lanes are waiting for;
+//   * per-sample results go to a [sample][pixel] buffer in HBM and are summed per pixel in the
+//     reference's order by a second kernel.
+#include <hip/hip_runtime.h>
+
+#include "rt_intersect.h"
+
+namespace rtd {
+
+enum QueryKind : int { Q_TRACE = 0, Q_SHADOW = 1, Q_PHOTON = 2 };
+enum LaneState : int { S_IDLE = 0, S_QUERY = 1, S_MARCH = 2, S_NORMAL = 3, S_RESOLVE = 4 };
+
+constexpr int kFrameFields = 11;
+
+struct Counters {
+    unsigned long long v[C_COUNT];
+};
+
+// Everything one lane carries between phases.
+struct Lane {
+    int state;
+    // current query
+    V3 qo, qd;
+    float qmax;
+    int qkind;
+    bool qactive;    // still testing objects (false once a shadow ray is blocked)
+    bool blocked;
+    // best accepted hit of the current query
+    bool found;
+    HitRec best;
+    unsigned best_obj;
+    float best_cos;
+    // Julia march
+    unsigned jidx, jstep;
+    V3 jp, jd;
+    // current node of the ray tree
+    V3 n_point, n_normal, n_dir;
+    V2 n_ph;
+    float n_cos;
+    unsigned n_obj;
+    float acc[3], matcol[3];
+    unsigned li;
+    // sample
+    unsigned sp;             // frames on the stack == depth of the current node
+    float wavelength;
+    int hue;                 // -1 without dispersion
+    unsigned long long out_slot;
+};
+
+template <bool STATS>
+RT_DEV void bump(Counters& n, int slot, unsigned long long by = 1) {
+    if (STATS) n.v[slot] += by;
+}
+
+// A candidate hit of scene object `obj` reaches the per-query acceptance rule
+// (src/raytracer.cpp:128-141 for Q_TRACE, :222-226 for Q_SHADOW, src/photonmap.cpp:68-74 for Q_PHOTON).
+RT_DEV void accept_hit(Lane& L, const HitRec& h, unsigned obj, float transmittance, float refr_norm) {
+    if (L.qkind == Q_SHADOW) {
+        if (dot(L.qd, h.normal) < 0.0f) {   // only front faces cast shadows
+            L.blocked = true;
+            L.qactive = false;
+        }
+        return;
+    }
+    float cosv = 0.0f;
+    if (L.qkind == Q_TRACE) {
+        cosv = clampf(dot(L.qd, h.normal), -1.0f, 1.0f);
+        if (cosv >= 0.0f && (transmittance == 0.0f || refr_norm == 0.0f)) return;   // unseen back face
+    }
+    L.found = true;
+    L.best = h;
+    L.best_obj = obj;
+    L.best_cos = cosv;
+    L.qmax = h.dist;
+}
+
+// The wave-uniform object loop: every lane with L.qactive tests its ray against every non-Julia
+// object in scene order.  `runs`, the geometry tables and the material flags are read at uniform
+// addresses.
+template <bool STATS>
+RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, Counters& n) {
+    bool active = in_phase && L.qactive;
+    for (unsigned r = 0; r < sc.n_runs; r++) {
+        const DevRun run = sc.runs[r];
+        if (run.kind == RUN_TRIANGLES) {
+            for (unsigned i = 0; i < run.count; i++) {
+                if (!__any(active)) break;
+                const DevTriTest& tt = sc.tri_test[run.first_prim + i];
+                if (active) {
+                    bump<STATS>(n, C_TRIANGLE_TESTS);
+                    float u, v, t;
+                    if (tri_test(tt, L.qo, L.qd, L.qmax, u, v, t)) {
+                        HitRec h;
+                        tri_finish(sc.tri_shade[run.first_prim + i], L.qo, L.qd, u, v, t, h);
+                        const DevMaterial& m = sc.materials[sc.object_material[run.first_object + i]];
+                        accept_hit(L, h, run.first_object + i, m.transmittance, m.refr_norm);
+                        active = L.qactive;
+                    }
+                }
+            }
+        } else if (run.kind == RUN_SPHERES) {
+            for (unsigned i = 0; i < run.count; i++) {
+                if (!__any(active)) break;
+                const DevSphere& s = sc.spheres[run.first_prim + i];
+                if (active) {
+                    bump<STATS>(n, C_SPHERE_TESTS);
+                    HitRec h;
+                    if (sphere_intersect(s, L.qo, L.qd, L.qmax, h)) {
+                        const DevMaterial& m = sc.materials[sc.object_material[run.first_object + i]];
+                        accept_hit(L, h, run.first_object + i, m.transmittance, m.refr_norm);
+                        active = L.qactive;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Julia hits are judged after the uniform loop; the rule below is the order-independent form of the
+// reference's sequential one (nearest wins, equal distances go to the later scene object).
+RT_DEV void accept_julia_hit(Lane& L, const HitRec& h, const DevJulia& j, const DevMaterial& m) {
+    if (L.qkind != Q_SHADOW) {
+        const bool nearer = h.dist < L.qmax || (h.dist == L.qmax && (!L.found || j.object > L.best_obj));
+        if (!nearer) return;
+    }
+    accept_hit(L, h, j.object, m.transmittance, m.refr_norm);
+}
+
+RT_DEV void begin_query(Lane& L, V3 o, V3 d, float maxd, int kind) {
+    L.qo = o;
+    L.qd = d;
+    L.qmax = maxd;
+    L.qkind = kind;
+    L.qactive = true;
+    L.blocked = false;
+    L.found = false;
+    L.state = S_QUERY;
+}
+
+// ---- frame stack in HBM ---------------------------------------------------------------------------
+struct FrameRef {
+    float* base;
+    unsigned long long stride;   // lanes in the grid
+    RT_DEV float& at(unsigned frame, int field) const { return base[(static_cast<unsigned long long>(frame) * kFrameFields + field) * stride]; }
+};
+
+// ---- sample queue ---------------------------------------------------------------------------------
+// Lanes with `need` set get consecutive sample ids (one atomic per wave and call).
+RT_DEV bool fetch_ids(unsigned long long* head, unsigned long long limit, bool need, unsigned long long& id) {
+    const unsigned long long mask = __ballot(need);
+    if (!need) return false;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+    const unsigned cnt = __popcll(mask);
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(head, static_cast<unsigned long long>(cnt));
+    base = __shfl(base, leader);
+    const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
+    id = base + rank;
+    return id < limit;
+}
+
+RT_DEV unsigned hash_u32(unsigned x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+// Decodes a sample id and builds its camera ray (src/raytracer.cpp:56-93).  Returns false for the
+// padding lanes of edge tiles.
+RT_DEV bool start_sample(const DevScene& sc, const DevJob& job, unsigned long long id, Lane& L) {
+    const unsigned p = static_cast<unsigned>(id & 63ull);
+    const unsigned long long q = id >> 6;
+    const unsigned s = static_cast<unsigned>(q % job.samples_per_pixel);
+    const unsigned tile = static_cast<unsigned>(q / job.samples_per_pixel);
+    const unsigned x = (tile % job.tiles_x) * 8 + (p & 7), yc = (tile / job.tiles_x) * 8 + (p >> 3);
+    if (x >= sc.width || yc >= job.compact_rows) return false;
+    const unsigned y = (job.first_band + (yc / job.band_rows) * job.band_stride) * job.band_rows + yc % job.band_rows;
+    const unsigned hues = sc.dispersion ? 8u : 1u;
+    const unsigned hue = s % hues, sub = s / hues;
+    const unsigned sx = sub % sc.supersampling, sy = sub / sc.supersampling;
+    const float sdx = sc.sub_disp[sx], sdy = sc.sub_disp[sy];
+    const V3 on_plane = {sc.ray_x[x] + sdx * sc.pixel_size[0], sc.ray_y[y] + sdy * sc.pixel_size[1], -1.0f};
+    const V3 on_focus = xform_point(sc.cam, on_plane * sc.focus_distance);
+    // lens jitter: the reference draws from a std::minstd_rand seeded by std::random_device per worker
+    // (not reproducible); here the draw is a hash of (pixel, sub-pixel, seed).  With
+    // lens_size == 0 the product is zero either way.
+    const unsigned h1 = hash_u32((y * sc.width + x) * 64u + sub + job.dof_seed * 0x9e3779b9u), h2 = hash_u32(h1 ^ 0x68bc21ebu);
+    const float r1 = static_cast<float>(h1 >> 8) * (2.0f / 16777216.0f) - 1.0f, r2 = static_cast<float>(h2 >> 8) * (2.0f / 16777216.0f) - 1.0f;
+    const float inv_n = 1.0f / static_cast<float>(sc.supersampling);
+    const float lx = (sdx + r1 * inv_n) * sc.lens_size, ly = (sdy + r2 * inv_n) * sc.lens_size;
+    V3 origin = xform_point(sc.cam, v3(0.0f, 0.0f, 0.0f));
+    origin = {origin.x + lx, origin.y + ly, origin.z};
+    L.sp = 0;
+    L.hue = sc.dispersion ? static_cast<int>(hue) : -1;
+    L.wavelength = sc.dispersion ? (static_cast<float>(hue) * 45.0f) / 180.0f - 1.0f : 0.0f;
+    L.out_slot = static_cast<unsigned long long>(s) * job.n_pixels + static_cast<unsigned long long>(yc) * sc.width + x;
+    begin_query(L, origin, normalized(on_focus - origin), kInfinite, Q_TRACE);
+    return true;
+}
+
+// Stores a finished primary sample (src/raytracer.cpp:100-110).
+RT_DEV void store_sample(const DevScene& sc, const DevJob& job, const Lane& L, Col value) {
+    Col contrib = value;
+    if (L.hue >= 0) {
+        const Col hc = {sc.hue[L.hue][0], sc.hue[L.hue][1], sc.hue[L.hue][2], sc.hue[L.hue][3]};
+        contrib = (value * hc) / 4.0f;
+    }
+    if (job.samples_per_pixel == 1) {
+        const Col zero = {0.0f, 0.0f, 0.0f, 0.0f};
+        const Col px = zero + (zero + contrib) * sc.inv_samples;
+        job.out[L.out_slot] = make_float4(px.r, px.g, px.b, px.a);
+    } else {
+        job.samples[L.out_slot] = make_float4(contrib.r, contrib.g, contrib.b, contrib.a);
+    }
+}
+
+// Shadow query towards light L.li from the current node (src/raytracer.cpp:214-220).
+RT_DEV void begin_shadow(const DevScene& sc, Lane& L) {
+    const DevLight& light = sc.lights[L.li];
+    const V3 lpos = v3(light.position[0], light.position[1], light.position[2]);
+    const V3 dir = normalized(light.type == 0 ? lpos * -1.0f : lpos - L.n_point);
+    const V3 origin = L.n_point + L.n_normal * kEpsilon;
+    const float ldist = light.type == 0 ? kInfinite : length(lpos - origin);
+    begin_query(L, origin, dir, ldist, Q_SHADOW);
+}
+
+// ---- resolve phase: advance one lane's ray tree by one query result ---------------------------------
+template <bool STATS>
+RT_DEV void resolve_lane(const DevScene& sc, const DevJob& job, const FrameRef& stack, Lane& L, Counters& n,
+                         bool& sample_done, Col& sample_value) {
+    bool lights_done = false;
+    bool returning = false;
+    float val[3] = {0.0f, 0.0f, 0.0f};
+    float val_a = 0.0f;
+
+    if (L.qkind == Q_TRACE) {
+        bump<STATS>(n, L.sp == 0 ? C_PRIMARY : C_SECONDARY);
+        if (!L.found) {
+            val[0] = sc.background[0];
+            val[1] = sc.background[1];
+            val[2] = sc.background[2];
+            val_a = sc.background[3];
+            returning = true;
+        } else {
+            bump<STATS>(n, C_SHADED_HITS);
+            L.n_point = L.best.point;
+            L.n_normal = L.best.normal;
+            L.n_dir = L.qd;
+            L.n_cos = L.best_cos;
+            L.n_obj = L.best_obj;
+            L.n_ph = L.best.ph;
+            L.acc[0] = L.acc[1] = L.acc[2] = 0.0f;
+            L.li = 0;
+            if (L.n_cos < 0.0f) {
+                const DevMaterial& m = sc.materials[sc.object_material[L.n_obj]];
+                Col mc = {m.color[0], m.color[1], m.color[2], m.color[3]};
+                if (m.texture >= 0) {
+                    bump<STATS>(n, C_TEXTURE_LOOKUPS);
+                    mc = texture_bilinear(sc.textures[m.texture], sc.texels, L.best.uv);
+                }
+                L.matcol[0] = mc.r;
+                L.matcol[1] = mc.g;
+                L.matcol[2] = mc.b;
+                // rad += ambient * materialColor * ka   (src/raytracer.cpp:212)
+                L.acc[0] = 0.0f + sc.ambient[0] * mc.r * m.ka;
+                L.acc[1] = 0.0f + sc.ambient[1] * mc.g * m.ka;
+                L.acc[2] = 0.0f + sc.ambient[2] * mc.b * m.ka;
+            } else {
+                lights_done = true;   // back side of a transparent object: no Phong, no photons
+            }
+        }
+    } else {   // Q_SHADOW result for light L.li (src/raytracer.cpp:227-235)
+        bump<STATS>(n, C_SHADOW);
+        bump<STATS>(n, C_PHONG_LIGHTS);
+        if (!L.blocked) {
+            const DevMaterial& m = sc.materials[sc.object_material[L.n_obj]];
+            const DevLight& light = sc.lights[L.li];
+            const float ndotl = dot(L.qd, L.n_normal);
+            const float lambert = ndotl < 0.0f ? 0.0f : ndotl;   // std::max(x, 0.0f)
+            const V3 refl = normalized(L.n_normal * ndotl * 2.0f - L.qd);
+            const float rv = dot(refl, L.n_dir * -1.0f);
+            const float sbase = rv < 0.0f ? 0.0f : rv;
+            const float spow = static_cast<float>(pow(static_cast<double>(sbase), static_cast<double>(m.exponent)));   // Y8
+            for (int c = 0; c < 3; c++) {
+                const float diffuse = light.power[c] * L.matcol[c] * lambert * m.kd;
+                const float specular = light.power[c] * spow * m.ks;
+                L.acc[c] = L.acc[c] + (diffuse + specular);
+            }
+        }
+        L.li++;
+    }
+
+    if (!returning && !lights_done) {
+        if (L.li < sc.n_lights) {
+            begin_shadow(sc, L);
+            return;
+        }
+        // rad += object.getPhoton(photonCoordinate)   (src/raytracer.cpp:146)
+        const int slot = sc.object_photon_slot[L.n_obj];
+        if (slot >= 0 && sc.photon_atlas != nullptr) {
+            const unsigned texel = photon_texel(L.n_ph, sc.photon_size);
+            const float4 ph = sc.photon_atlas[static_cast<size_t>(slot) * sc.photon_size * sc.photon_size + texel];
+            L.acc[0] += ph.x;
+            L.acc[1] += ph.y;
+            L.acc[2] += ph.z;
+        }
+        lights_done = true;
+    }
+
+    if (!returning) {
+        // Fresnel split (src/raytracer.cpp:151-159)
+        const DevMaterial& m = sc.materials[sc.object_material[L.n_obj]];
+        bool descended = false;
+        if ((m.transmittance != 0.0f || m.reflectance != 0.0f) && m.refr_norm > 0.0f) {
+            bump<STATS>(n, C_FRESNEL);
+            const float kr = fresnel_kr(m.refr_re, m.refr_im, m.dispersion, L.n_cos, L.wavelength);
+            const bool want_refr = m.transmittance != 0.0f && kr < 1.0f;
+            const bool want_refl = m.reflectance != 0.0f && kr > 0.0f;
+            // a child at depth sp+1 > max_bounces returns zero radiance: nothing to add
+            if (L.sp + 1 <= sc.max_bounces && (want_refr || want_refl)) {
+                V3 ro, rd, mo, md;
+                const bool refr_ok = want_refr && refraction_ray(L.n_dir, L.n_point, L.n_normal, m.refr_re, m.dispersion, L.n_cos, L.wavelength, ro, rd);
+                if (want_refl) reflection_ray(L.n_dir, L.n_point, L.n_normal, L.n_cos, mo, md);
+                if (refr_ok || want_refl) {
+                    const unsigned f = L.sp;
+                    stack.at(f, 0) = L.acc[0];
+                    stack.at(f, 1) = L.acc[1];
+                    stack.at(f, 2) = L.acc[2];
+                    stack.at(f, 3) = kr;
+                    if (refr_ok && want_refl) {
+                        stack.at(f, 4) = mo.x;
+                        stack.at(f, 5) = mo.y;
+                        stack.at(f, 6) = mo.z;
+                        stack.at(f, 7) = md.x;
+                        stack.at(f, 8) = md.y;
+                        stack.at(f, 9) = md.z;
+                    }
+                    // flags: bit0 = the child now in flight is the reflection, bit1 = reflection still to do
+                    stack.at(f, 10) = __uint_as_float(refr_ok ? (want_refl ? 2u : 0u) : 1u);
+                    L.sp = f + 1;
+                    if (refr_ok) begin_query(L, ro, rd, kInfinite, Q_TRACE); else begin_query(L, mo, md, kInfinite, Q_TRACE);
+                    descended = true;
+                }
+            }
+        }
+        if (descended) return;
+        val[0] = L.acc[0];
+        val[1] = L.acc[1];
+        val[2] = L.acc[2];
+        val_a = 1.0f;   // withoutAlpha
+    }
+
+    // return `val` to the parent frames (src/raytracer.cpp:153-160)
+    for (;;) {
+        if (L.sp == 0) {
+            sample_done = true;
+            sample_value = {val[0], val[1], val[2], val_a};
+            L.state = S_IDLE;
+            return;
+        }
+        const unsigned f = L.sp - 1;
+        const unsigned flags = __float_as_uint(stack.at(f, 10));
+        const float kr = stack.at(f, 3);
+        const float w = (flags & 1u) ? kr : 1.0f - kr;
+        float acc[3];
+        for (int c = 0; c < 3; c++) acc[c] = stack.at(f, c) + val[c] * w;
+        if (flags & 2u) {
+            // refraction child done, reflection child next
+            for (int c = 0; c < 3; c++) stack.at(f, c) = acc[c];
+            stack.at(f, 10) = __uint_as_float(1u);
+            const V3 mo = v3(stack.at(f, 4), stack.at(f, 5), stack.at(f, 6));
+            const V3 md = v3(stack.at(f, 7), stack.at(f, 8), stack.at(f, 9));
+            begin_query(L, mo, md, kInfinite, Q_TRACE);
+            return;
+        }
+        L.sp = f;
+        val[0] = acc[0];
+        val[1] = acc[1];
+        val[2] = acc[2];
+        val_a = 1.0f;
+    }
+}
+
+template <bool STATS>
+RT_DEV void flush_counters(const Counters& n, unsigned long long* out) {
+    if (!STATS) return;
+    for (int i = 0; i < C_COUNT; i++) {
+        unsigned long long v = n.v[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&out[i], v);
+    }
+}
+
+// ---- the render kernel ------------------------------------------------------------------------------
+template <bool HAS_JULIA, bool STATS>
+__global__ __launch_bounds__(256) void trace_kernel(const DevScene sc, const DevJob job) {
+    Counters n;
+    if (STATS) for (int i = 0; i < C_COUNT; i++) n.v[i] = 0;
+    const unsigned long long grid_lanes = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
+    const unsigned long long gid = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const FrameRef stack = {job.stack + gid, grid_lanes};
+
+    Lane L;
+    L.state = S_RESOLVE;       // "resolve" of a lane without a sample = fetch one
+    L.qkind = -1;
+    L.sp = 0;
+    L.jidx = 0;
+    L.jstep = 0;
+    bool fresh = true;         // lane holds no sample yet
+
+    for (;;) {
+        // ---- pick the phase most lanes are waiting for --------------------------------------------
+        int phase;
+        if (HAS_JULIA) {
+            const int n_query = __popcll(__ballot(L.state == S_QUERY));
+            const int n_march = __popcll(__ballot(L.state == S_MARCH));
+            const int n_normal = __popcll(__ballot(L.state == S_NORMAL));
+            const int n_resolve = __popcll(__ballot(L.state == S_RESOLVE));
+            if (n_query + n_march + n_normal + n_resolve == 0) break;
+            phase = S_MARCH;
+            int best = n_march;
+            if (n_normal > best) { best = n_normal; phase = S_NORMAL; }
+            if (n_resolve > best) { best = n_resolve; phase = S_RESOLVE; }
+            if (n_query > best) { best = n_query; phase = S_QUERY; }
+        } else {
+            // without Julia sets every lane alternates query -> resolve in lockstep
+            const bool any_query = __any(L.state == S_QUERY);
+            const bool any_resolve = __any(L.state == S_RESOLVE);
+            if (!any_query && !any_resolve) break;
+            phase = any_query ? S_QUERY : S_RESOLVE;
+        }
+
+        if (phase == S_QUERY) {
+            const bool mine = L.state == S_QUERY;
+            query_objects<STATS>(sc, L, mine, n);
+            if (mine) {
+                if (HAS_JULIA && sc.n_julias > 0 && L.qactive) {
+                    L.jidx = 0;
+                    L.state = S_MARCH;
+                    L.jstep = 0xffffffffu;   // not entered yet
+                } else {
+                    L.state = S_RESOLVE;
+                }
+            }
+        } else if (HAS_JULIA && phase == S_MARCH) {
+            if (L.state == S_MARCH) {
+                const DevJulia& j = sc.julias[L.jidx];
+                bool next_object = false;
+                if (L.jstep == 0xffffffffu) {
+                    bump<STATS>(n, C_JULIA_QUERIES);
+                    if (julia_enter(j, L.qo, L.qd, L.jp, L.jd)) L.jstep = 0; else next_object = true;
+                }
+                if (!next_object) {
+                    bump<STATS>(n, C_JULIA_STEPS);
+                    unsigned long long iters = 0;
+                    const int r = julia_step<STATS>(j, L.jp, L.jd, L.jstep, iters);
+                    bump<STATS>(n, C_JULIA_DE_ITERATIONS, iters);
+                    if (r == 1) L.state = S_NORMAL;
+                    if (r == 2) next_object = true;
+                }
+                if (next_object) {
+                    L.jidx++;
+                    L.jstep = 0xffffffffu;
+                    if (L.jidx >= sc.n_julias) L.state = S_RESOLVE;
+                }
+            }
+        } else if (HAS_JULIA && phase == S_NORMAL) {
+            if (L.state == S_NORMAL) {
+                const DevJulia& j = sc.julias[L.jidx];
+                bump<STATS>(n, C_JULIA_NORMALS);
+                unsigned long long iters = 0;
+                HitRec h;
+                // Julia::intersect ignores max_distance until this final check (src/objects.cpp:236)
+                const float limit = L.qkind == Q_SHADOW ? L.qmax : kInfinite;
+                if (julia_finish<STATS>(j, L.qo, L.jp, L.jd, limit, h, iters)) accept_julia_hit(L, h, j, sc.materials[j.material]);
+                bump<STATS>(n, C_JULIA_DE_ITERATIONS, iters);
+                L.jidx++;
+                L.jstep = 0xffffffffu;
+                L.state = (L.jidx >= sc.n_julias || !L.qactive) ? S_RESOLVE : S_MARCH;
+            }
+        } else {   // S_RESOLVE
+            const bool mine = L.state == S_RESOLVE;
+            bool done = false;
+            Col value = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (mine && !fresh) resolve_lane<STATS>(sc, job, stack, L, n, done, value);
+            if (mine && done) store_sample(sc, job, L, value);
+            bool need = mine && (fresh || done);
+            if (need) L.state = S_IDLE;
+            // refill from the queue; padding lanes of edge tiles simply ask again
+            while (__any(need)) {
+                unsigned long long id = 0;
+                const bool got = fetch_ids(job.queue_head, job.n_samples, need, id);
+                if (need) {
+                    if (!got) {
+                        need = false;   // queue is exhausted: this lane stays idle
+                    } else if (start_sample(sc, job, id, L)) {
+                        need = false;
+                        fresh = false;
+                    }
+                }
+            }
+        }
+    }
+    flush_counters<STATS>(n, job.counters);
+}
+
+// ---- per-pixel sum of the samples, in the reference's order (src/raytracer.cpp:61-110) ------------
+__global__ __launch_bounds__(256) void sum_samples_kernel(const float4* __restrict__ samples, float4* __restrict__ out,
+                                                          unsigned long long n_pixels, unsigned samples_per_pixel, float inv_samples) {
+    const unsigned long long p = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p >= n_pixels) return;
+    Col rad = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (unsigned s = 0; s < samples_per_pixel; s++) {
+        const float4 c = samples[static_cast<unsigned long long>(s) * n_pixels + p];
+        rad = rad + Col{c.x, c.y, c.z, c.w};
+    }
+    const Col zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    const Col px = zero + rad * inv_samples;
+    out[p] = make_float4(px.r, px.g, px.b, px.a);
+}
+
+// ---- photon pass (src/photonmap.cpp:20-146) ---------------------------------------------------------
+// One lane = one root direction (light, phi, theta, hue).  The path tree is walked depth first with
+// a stack of pending rays; deposits are float atomics into the photon atlas (their order is not the
+// reference's sequential one: texels agree to rounding, not bit for bit).
+template <bool HAS_JULIA, bool STATS>
+__global__ __launch_bounds__(256) void photon_kernel(const DevScene sc, const DevPhotonJob job) {
+    Counters n;
+    if (STATS) for (int i = 0; i < C_COUNT; i++) n.v[i] = 0;
+    const unsigned long long grid_lanes = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
+    const unsigned long long gid = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const FrameRef stack = {job.stack + gid, grid_lanes};
+
+    Lane L;
+    L.state = S_IDLE;
+    L.sp = 0;
+    float rad[4] = {0, 0, 0, 0};
+    unsigned depth = 0;
+    bool need = true;
+    for (;;) {
+        // refill idle lanes with new roots
+        while (__any(need)) {
+            unsigned long long id = 0;
+            const bool got = fetch_ids(job.queue_head, job.n_roots, need, id);
+            if (need) {
+                need = false;
+                if (got) {
+                    const unsigned hue = static_cast<unsigned>(id % job.hues);
+                    unsigned long long q = id / job.hues;
+                    const unsigned ti = static_cast<unsigned>(q % job.n_theta);
+                    q /= job.n_theta;
+                    const unsigned pi = static_cast<unsigned>(q % job.n_phi);
+                    const unsigned li = static_cast<unsigned>(q / job.n_phi);
+                    const DevLight& light = sc.lights[job.point_lights[li]];
+                    const float st = job.sin_theta[ti], ct = job.cos_theta[ti], sp_ = job.sin_phi[pi], cp = job.cos_phi[pi];
+                    const V3 dir = normalized(v3(st * cp, st * sp_, ct));
+                    if (sc.dispersion) {
+                        // HSVtoRGB(h) * factor / 4
+                        for (int c = 0; c < 4; c++) rad[c] = (sc.hue[hue][c] * sc.photon_factor) / 4.0f;
+                        L.wavelength = (static_cast<float>(hue) * 45.0f) / 180.0f - 1.0f;
+                    } else {
+                        for (int c = 0; c < 4; c++) rad[c] = 1.0f * sc.photon_factor;
+                        L.wavelength = 0.0f;
+                    }
+                    depth = 0;
+                    L.sp = 0;
+                    begin_query(L, v3(light.position[0], light.position[1], light.position[2]), dir, kInfinite, Q_PHOTON);
+                }
+            }
+        }
+        if (!__any(L.state == S_QUERY)) break;
+
+        const bool mine = L.state == S_QUERY;
+        query_objects<STATS>(sc, L, mine, n);
+        if (mine) {
+            bump<STATS>(n, C_PHOTON_SEGMENTS);
+            if (HAS_JULIA) {
+                for (unsigned k = 0; k < sc.n_julias; k++) {
+                    const DevJulia& j = sc.julias[k];
+                    HitRec h;
+                    unsigned long long steps = 0, iters = 0;
+                    bump<STATS>(n, C_JULIA_QUERIES);
+                    if (julia_intersect_inline<STATS>(j, L.qo, L.qd, kInfinite, h, steps, iters)) accept_julia_hit(L, h, j, sc.materials[j.material]);
+                    bump<STATS>(n, C_JULIA_STEPS, steps);
+                    bump<STATS>(n, C_JULIA_DE_ITERATIONS, iters);
+                }
+            }
+            bool pop = true;
+            if (L.found) {
+                const DevMaterial& m = sc.materials[sc.object_material[L.best_obj]];
+                if (m.refr_norm <= 0.0f) {
+                    // the light ray ends on a diffuse object (src/photonmap.cpp:79-83)
+                    const int slot = sc.object_photon_slot[L.best_obj];
+                    if (depth > 0 && slot >= 0) {
+                        bump<STATS>(n, C_PHOTON_DEPOSITS);
+                        const unsigned texel = photon_texel(L.best.ph, sc.photon_size);
+                        float* t = reinterpret_cast<float*>(sc.photon_atlas + static_cast<size_t>(slot) * sc.photon_size * sc.photon_size + texel);
+                        atomicAdd(t + 0, rad[0]);
+                        atomicAdd(t + 1, rad[1]);
+                        atomicAdd(t + 2, rad[2]);
+                        atomicAdd(t + 3, rad[3]);
+                    }
+                } else if (depth + 1 <= sc.max_bounces) {
+                    const float cosv = clampf(dot(L.qd, L.best.normal), -1.0f, 1.0f);
+                    bump<STATS>(n, C_FRESNEL);
+                    const float kr = fresnel_kr(m.refr_re, m.refr_im, m.dispersion, cosv, L.wavelength);
+                    V3 ro, rd, mo, md;
+                    const bool refr_ok = kr < 1.0f && refraction_ray(L.qd, L.best.point, L.best.normal, m.refr_re, m.dispersion, cosv, L.wavelength, ro, rd);
+                    reflection_ray(L.qd, L.best.point, L.best.normal, cosv, mo, md);
+                    if (refr_ok) {
+                        // reflection (always cast, src/photonmap.cpp:141-144) waits on the stack
+                        const unsigned f = L.sp;
+                        stack.at(f, 0) = mo.x; stack.at(f, 1) = mo.y; stack.at(f, 2) = mo.z;
+                        stack.at(f, 3) = md.x; stack.at(f, 4) = md.y; stack.at(f, 5) = md.z;
+                        for (int c = 0; c < 4; c++) stack.at(f, 6 + c) = rad[c] * kr;
+                        stack.at(f, 10) = __uint_as_float(depth + 1);
+                        L.sp = f + 1;
+                        for (int c = 0; c < 4; c++) rad[c] = rad[c] * (1 - kr);
+                        begin_query(L, ro, rd, kInfinite, Q_PHOTON);
+                    } else {
+                        for (int c = 0; c < 4; c++) rad[c] = rad[c] * kr;
+                        begin_query(L, mo, md, kInfinite, Q_PHOTON);
+                    }
+                    depth = depth + 1;
+                    pop = false;
+                }
+            }
+            if (pop) {
+                if (L.sp > 0) {
+                    const unsigned f = L.sp - 1;
+                    const V3 o = v3(stack.at(f, 0), stack.at(f, 1), stack.at(f, 2));
+                    const V3 d = v3(stack.at(f, 3), stack.at(f, 4), stack.at(f, 5));
+                    for (int c = 0; c < 4; c++) rad[c] = stack.at(f, 6 + c);
+                    depth = __float_as_uint(stack.at(f, 10));
+                    L.sp = f;
+                    begin_query(L, o, d, kInfinite, Q_PHOTON);
+                } else {
+                    L.state = S_IDLE;
+                    need = true;
+                }
+            }
+        }
+    }
+    flush_counters<STATS>(n, job.counters);
+}
+
+// ---- known-answer kernels: one function of the path per lane ----------------------------------------
+// Object::intersect for (object, origin, direction, max) records; out = hit flag + 11 floats.
+__global__ void kat_intersect_kernel(const DevScene sc, const unsigned* __restrict__ kind, const unsigned* __restrict__ prim,
+                                     const float* __restrict__ rays, unsigned n, float* __restrict__ out) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + static_cast<size_t>(i) * 7;
+    const V3 o = v3(r[0], r[1], r[2]);
+    const V3 d = normalized(v3(r[3], r[4], r[5]));   // the Ray constructor normalises
+    const float maxd = r[6];
+    HitRec h = {};
+    bool hit = false;
+    if (kind[i] == 0) {
+        hit = sphere_intersect(sc.spheres[prim[i]], o, d, maxd, h);
+    } else if (kind[i] == 1) {
+        float u, v, t;
+        if (tri_test(sc.tri_test[prim[i]], o, d, maxd, u, v, t)) {
+            tri_finish(sc.tri_shade[prim[i]], o, d, u, v, t, h);
+            hit = true;
+        }
+    } else {
+        unsigned long long a = 0, b = 0;
+        hit = julia_intersect_inline<false>(sc.julias[prim[i]], o, d, maxd, h, a, b);
+    }
+    float* w = out + static_cast<size_t>(i) * 12;
+    w[0] = hit ? 1.0f : 0.0f;
+    w[1] = h.dist;
+    w[2] = h.point.x; w[3] = h.point.y; w[4] = h.point.z;
+    w[5] = h.normal.x; w[6] = h.normal.y; w[7] = h.normal.z;
+    w[8] = h.uv.x; w[9] = h.uv.y; w[10] = h.ph.x; w[11] = h.ph.y;
+}
+
+// calcFresnel for (re, im, dispersion, cos, wavelength) records
+__global__ void kat_fresnel_kernel(const float* __restrict__ in, unsigned n, float* __restrict__ out) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = in + static_cast<size_t>(i) * 5;
+    out[i] = fresnel_kr(r[0], r[1], r[2], r[3], r[4]);
+}
+
+// ---- Picture::mulAdd and Color::scaleOut (src/types.h:372-376, 274-282) -----------------------------
+__global__ __launch_bounds__(256) void mul_add_kernel(float* __restrict__ acc, const float* __restrict__ src, float factor, unsigned long long n) {
+    const unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] = acc[i] + src[i] * factor;
+}
+
+__global__ __launch_bounds__(256) void quantize_kernel(const float4* __restrict__ rgba, uchar4* __restrict__ out, float gain, unsigned long long n) {
+    const unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = rgba[i];
+    auto q = [gain](float v) -> unsigned char {
+        const float s = clampf(v * gain, 0.0f, 1.0f) * 255.0f;
+        return static_cast<unsigned char>(s != s ? 0.0f : s);   // truncation; NaN -> 0 like the x86 cast
+    };
+    out[i] = make_uchar4(q(c.x), q(c.y), q(c.z), q(c.w));
+}
+
+// explicit instantiations used by rt_api.hip
+template __global__ void trace_kernel<false, false>(const DevScene, const DevJob);
+template __global__ void trace_kernel<false, true>(const DevScene, const DevJob);
+template __global__ void trace_kernel<true, false>(const DevScene, const DevJob);
+template __global__ void trace_kernel<true, true>(const DevScene, const DevJob);
+template __global__ void photon_kernel<false, false>(const DevScene, const DevPhotonJob);
+template __global__ void photon_kernel<false, true>(const DevScene, const DevPhotonJob);
+template __global__ void photon_kernel<true, false>(const DevScene, const DevPhotonJob);
+template __global__ void photon_kernel<true, true>(const DevScene, const DevPhotonJob);
+
+}  // namespace rtd

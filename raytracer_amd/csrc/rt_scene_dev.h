@@ -1,0 +1,154 @@
+// Device-resident scene layout (HBM) shared by rt_api.hip and the kernels.
+//
+// All of it is a few KB to a few MB: geometry tables are read with wave-uniform indices (scalar
+// loads, SGPR operands) inside the object loops; shading tables, textures and the photon atlas are
+// read per lane.  Tables are 16-byte aligned records so a uniform record is one or two s_load_dwordx8.
+#pragma once
+
+#include <stdint.h>
+
+namespace rtd {
+
+enum RunKind : int { RUN_SPHERES = 0, RUN_TRIANGLES = 1, RUN_TRIANGLE_BVH = 2 };
+
+// A maximal run of consecutive scene objects of one kind (scene order is preserved across runs).
+struct DevRun {
+    int kind;
+    uint32_t first_object;   // index into the per-object tables (= position in Scene::objects())
+    uint32_t first_prim;     // index into the per-kind geometry table
+    uint32_t count;
+    uint32_t bvh_root;       // RUN_TRIANGLE_BVH: first node of this run's BVH
+    uint32_t material;       // RUN_TRIANGLE_BVH: the run's single material
+    uint32_t pad0, pad1;
+};
+
+// What the Möller–Trumbore test needs (edges precomputed with the reference's own subtraction,
+// src/objects.cpp:56-57).  48 bytes.
+struct DevTriTest {
+    float p0[3], e1[3], e2[3];
+    float pad[3];
+};
+// What shading a triangle hit needs.  64 bytes.
+struct DevTriShade {
+    float n0[3], n1[3], n2[3];
+    float uv0[2], uv1[2], uv2[2];
+    float pad;
+};
+// 160 bytes
+struct DevSphere {
+    float center[3];
+    float radius;
+    float w2o[12], o2w[12], o2wn[12];
+};
+// 192 bytes
+struct DevJulia {
+    float position[3];
+    float scale;
+    float c[4];
+    float cut_plane;
+    float inv_scale;         // 1.0f / scale as the reference computes it (src/objects.cpp:165)
+    uint32_t object;         // position in Scene::objects()
+    uint32_t material;
+    float w2o[12], o2w[12], o2wn[12];
+};
+// 64 bytes
+struct DevMaterial {
+    float color[4];
+    int texture;
+    float ka, kd, ks, exponent;
+    float reflectance, transmittance;
+    float refr_re, refr_im, dispersion;
+    float refr_norm;         // re*re + im*im (std::norm)
+    float pad;
+};
+struct DevTexture {
+    uint32_t width, height;
+    uint32_t first_texel;    // into the float4 texel pool
+    uint32_t pad;
+};
+struct DevLight {
+    float position[3];
+    int type;
+    float power[4];
+};
+// 32-byte BVH node: leaf when count > 0
+struct DevBvhNode {
+    float lo[3];
+    uint32_t left_or_first;  // inner: index of left child (right = left+1); leaf: first entry in bvh_prims
+    float hi[3];
+    uint32_t count;
+};
+
+struct DevScene {
+    // camera constants precomputed on the host with the reference's expressions (src/raytracer.cpp:17-29)
+    float cam[12];
+    float pixel_size[2];
+    float focus_distance, lens_size;
+    const float* ray_x;          // [width]  rayX as accumulated along a row (src/raytracer.cpp:59,111)
+    const float* ray_y;          // [height]
+    const float* sub_disp;       // [supersampling] 2(i+1)/(n+1)-1
+    uint32_t width, height, supersampling, max_bounces;
+    float inv_samples;           // 1.0f/(n*n)
+    int dispersion;              // 0/1
+    float hue[8][4];             // rgb + 1
+    float background[4], ambient[4];
+
+    uint32_t n_lights, n_objects, n_runs, n_julias;
+    const DevLight* lights;
+    const DevRun* runs;
+    const DevTriTest* tri_test;
+    const DevTriShade* tri_shade;
+    const DevSphere* spheres;
+    const DevJulia* julias;
+    const uint32_t* object_material;   // [n_objects]
+    const int32_t* object_photon_slot; // [n_objects] slot in the photon atlas or -1
+    const DevMaterial* materials;
+    const DevTexture* textures;
+    const float4* texels;
+    const DevBvhNode* bvh_nodes;
+    const uint32_t* bvh_prims;         // triangle indices (into tri_test) in leaf order
+
+    float4* photon_atlas;              // [n_slots][size][size]
+    uint32_t photon_size;
+    float photon_factor;
+};
+
+// One render call's partition of the image (rt_bands) and where its samples go.
+struct DevJob {
+    uint32_t band_rows, first_band, band_stride;
+    uint32_t compact_rows;       // rows rendered by this call
+    uint32_t tiles_x, tiles_y;   // 8x8 tiles over the compact image
+    uint32_t samples_per_pixel;  // n*n*(8 if dispersion)
+    uint64_t n_samples;          // tiles_x*tiles_y*samples_per_pixel*64 (incl. padding lanes of edge tiles)
+    uint64_t n_pixels;           // compact_rows*width
+    float4* samples;             // [samples_per_pixel][n_pixels] or NULL when samples_per_pixel == 1
+    float4* out;                 // [n_pixels]
+    float* stack;                // per-lane DFS frames: [frame][field][grid lane]
+    unsigned long long* queue_head;
+    unsigned long long* counters;// rt_stats words (only touched when STATS)
+    uint32_t dof_seed;
+};
+
+// Photon emission job (src/photonmap.cpp:38-57)
+struct DevPhotonJob {
+    const float* sin_phi;   // tables produced by the host with the reference's float loop
+    const float* cos_phi;
+    const float* sin_theta;
+    const float* cos_theta;
+    uint32_t n_phi, n_theta;
+    uint32_t n_point_lights;
+    const uint32_t* point_lights;   // indices into lights
+    uint32_t hues;                  // 8 in dispersion mode else 1
+    uint64_t n_roots;               // n_point_lights*n_phi*n_theta*hues
+    float* stack;
+    unsigned long long* queue_head;
+    unsigned long long* counters;
+};
+
+enum CounterSlot : int {
+    C_PRIMARY = 0, C_SECONDARY, C_SHADOW, C_PHOTON_SEGMENTS, C_PHOTON_DEPOSITS, C_SPHERE_TESTS, C_TRIANGLE_TESTS,
+    C_JULIA_QUERIES, C_JULIA_STEPS, C_JULIA_DE_ITERATIONS, C_JULIA_NORMALS, C_SHADED_HITS, C_PHONG_LIGHTS,
+    C_FRESNEL, C_TEXTURE_LOOKUPS, C_BVH_NODE_VISITS, C_COUNT
+};
+
+}  // namespace rtd

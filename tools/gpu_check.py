@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Ad-hoc parity/timing probe: HIP path vs the oracle on scene files (developer tool, GPU box)."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from raytracer_amd import capi  # noqa: E402
+import oracle_lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("scenes", nargs="+")
+    ap.add_argument("--t", type=float, default=0.0)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--ss", type=int, default=0)
+    ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--stats", action="store_true")
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--save", default="")
+    args = ap.parse_args()
+    ctx = capi.Context(0)
+    for path in args.scenes:
+        sc = capi.Scene(path, args.t)
+        if args.width or args.height or args.ss:
+            sc.set_camera(args.width, args.height, args.ss)
+        ctx.upload(sc)
+        ctx.set_option(capi.RT_OPT_COLLECT_STATS, 1 if args.stats else 0)
+        pst = ctx.photon_generate()
+        img, st = ctx.render()
+        times = []
+        for _ in range(args.reps):
+            _, s2 = ctx.render()
+            times.append(s2.kernel_ms)
+        print("%s %dx%d ss%d: photon %.3f ms, render kernel ms %s" % (os.path.basename(path), sc.width, sc.height,
+              sc.desc.camera.supersampling, pst.kernel_ms, ["%.3f" % t for t in times]), flush=True)
+        if args.stats:
+            print("  hip stats", {k: v for k, v in st.as_dict().items() if v}, flush=True)
+        if args.save:
+            capi.png_write(args.save, capi.quantize(img))
+        if not args.no_oracle:
+            t0 = time.time()
+            ph = oracle_lib.Photons(sc) if sc.desc.photon_steps > 0 else None
+            t1 = time.time()
+            ref, ost = oracle_lib.render(sc, ph, threads=args.threads)
+            t2 = time.time()
+            neq = img.view(np.uint32) != ref.view(np.uint32)
+            print("  oracle photon %.2fs render %.2fs; float words differing %d of %d (pixels %d)" % (
+                t1 - t0, t2 - t1, int(neq.sum()), neq.size, int(neq.any(axis=2).sum())), flush=True)
+            print("  8-bit:", oracle_lib.image_diff(capi.quantize(img), capi.quantize(ref)), flush=True)
+            if args.stats:
+                od = ost.as_dict()
+                hd = st.as_dict()
+                print("  counter diffs", {k: (hd[k], od[k]) for k in od if k != "kernel_ms" and hd[k] != od[k]}, flush=True)
+            if ph is not None:
+                worst = 0.0
+                for o in range(sc.desc.n_objects):
+                    a = ctx.photon_download(o)
+                    b = ph.texture(o)
+                    if b.any() or a.any():
+                        worst = max(worst, float(np.abs(a - b).max() / max(1e-30, np.abs(b).max())))
+                print("  photon atlas worst rel err %.3e; deposits hip %d oracle %d" % (worst, pst.photon_deposits, ph.stats.photon_deposits), flush=True)
+
+
+if __name__ == "__main__":
+    main()
