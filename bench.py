@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py — rays/s of the trace path on N MI355X GPUs of one node.
+
+A "step" is one pass of the hot path over one batch: rt_photon_generate + rt_render of one frame of
+the workload on every rank, the frame quantised on the GPU (Color::scaleOut) and, for N > 1, gathered
+to rank 0 over RCCL.  The scene is uploaded (resident in HBM) before the timed region.
+
+Workload (config.workload): BASELINE.json configs[1], examples/example9.xml at 3840x2160 — the
+largest single-GPU configuration.  `--workload` selects another config for developer runs.
+
+N > 1: frames are independent units: every rank renders its own full frame per step and
+rank 0 collects the RGBA8 frames ("scaling": "weak").  value = rays of all ranks / max-over-ranks time.
+
+Ray counts come from a counters-enabled launch of the same kernels outside the timed region (the
+counters are pinned to the oracle's by tests/test_gpu_parity.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "c1": ("examples/example1.xml", 0.0, "C1 examples/example1.xml 512x512"),
+    "c2": ("examples/example9_4k.xml", 0.0, "C2 examples/example9.xml @3840x2160, 69 objects, 2 lights, 2 textures"),
+    "c3": ("examples2/8_fresnel_ss4.xml", 0.0, "C3 examples2/8_fresnel.xml 512x512, 4x4 supersampling x 8 hues"),
+    "c4": ("examples3/101_julia_shiny.xml", 0.0, "C4 examples3/101_julia_shiny.xml 960x600, 2x2 supersampling"),
+    "c5": ("examples3/103_caustic_animation.xml", 0.5, "C5 examples3/103_caustic_animation.xml frame t=0.5 (photon pass + render)"),
+}
+
+# Algorithmic FP32 operations per unit of work (SURVEY §8d hand counts of the reference source as
+# written; lower bounds where the survey gives a range — e.g. every triangle test is priced at its
+# cheapest exit).  Transcendentals and the FP64 sub-expressions are not counted.
+FLOPS = {"triangle_tests": 29, "sphere_tests": 59, "shaded_hits": 64, "phong_lights": 75, "fresnel_evals": 110,
+         "texture_lookups": 40, "primary_rays": 60, "secondary_rays": 37, "julia_de_iterations": 41,
+         "julia_steps": 11, "julia_normals": 36, "julia_queries": 30, "photon_segments": 37}
+PEAK_FP32_TFLOPS = 157.3   # MI355X FP32 vector peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_flops(stats_dict):
+    return float(sum(stats_dict.get(k, 0) * w for k, w in FLOPS.items()))
+
+
+def cpu_baseline(scene, n_rays_frame):
+    """The oracle (CPU restatement, "port") timed on this box's host cores on the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    cores = min(16, os.cpu_count() or 1)
+    cam = scene.desc.camera
+    # bounded sample: every k-th row so that the run stays within ~10-30 s of CPU work
+    step = 1
+    est_full = n_rays_frame / 2.5e6 / max(1, cores) * 8     # ~2.5 M rays/s on 8 cores in the build container
+    while est_full / step > 20.0:
+        step *= 2
+    t0 = time.time()
+    photons = oracle_lib.Photons(scene) if scene.desc.photon_steps > 0 else None
+    t_photon = time.time() - t0
+    t0 = time.time()
+    _, st = oracle_lib.render(scene, photons, threads=cores, rows=(0, cam.height, step))
+    dt = time.time() - t0 + t_photon
+    rays = st.total_rays() + (photons.stats.photon_segments if photons else 0)
+    return {"value": rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": "oracle/liboracle.so, every %d-th row of the frame (%d rows)%s, %.2f s" % (
+                step, (cam.height + step - 1) // step, " + serial photon pass" if photons else "", dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    rel, t, label = WORKLOADS[args.workload]
+    scene = capi.Scene(os.path.join(ROOT, "scenes", rel), t)
+    ctx = capi.Context(local_rank)
+    ctx.upload(scene)
+    w, h = scene.width, scene.height
+    n_pix = w * h
+    frame = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
+    frame8 = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
+    gathered = [torch.empty_like(frame8) for _ in range(world)] if (world > 1 and rank == 0) else None
+    stream = torch.cuda.current_stream().cuda_stream
+    has_photons = scene.desc.photon_steps > 0
+
+    # ---- counters (untimed): rays and algorithmic flops of one step on this rank ------------------
+    ctx.set_option(capi.RT_OPT_COLLECT_STATS, 1)
+    pst = ctx.photon_generate()
+    ctx.render_device(frame.data_ptr(), stream)
+    torch.cuda.synchronize()
+    rst = ctx.fetch_stats()
+    stats = {k: v + pst.as_dict()[k] for k, v in rst.as_dict().items() if k != "kernel_ms"}
+    rays_per_step = stats["primary_rays"] + stats["secondary_rays"] + stats["shadow_rays"] + stats["photon_segments"]
+    flops_per_step = algorithmic_flops(stats)
+    ctx.set_option(capi.RT_OPT_COLLECT_STATS, 0)
+
+    def step(events=None):
+        if has_photons:
+            ctx.photon_generate_device(stream)
+        if events is not None:
+            events[0].record()
+        ctx.render_device(frame.data_ptr(), stream)
+        if events is not None:
+            events[1].record()
+        ctx.quantize_device(frame.data_ptr(), frame8.data_ptr(), 1.0, n_pix, stream)
+        if world > 1:
+            dist.gather(frame8, gathered, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(events[i])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+
+    if rank == 0:
+        value = rays_per_step * world * args.steps / elapsed
+        achieved = flops_per_step / (kernel_ms * 1e-3) / 1e12
+        line = {
+            "metric": "rays/sec", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": label, "scene": rel, "t": t, "rays_per_frame": rays_per_step,
+                       "frames_per_step": world, "sec_per_frame": elapsed / args.steps,
+                       "parallelism": "frames sharded over ranks, RGBA8 frames gathered to rank 0 over RCCL" if world > 1 else "1 GPU"},
+            "roofline": {"bound": "valu", "kernel": "trace_kernel", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops_per_step,
+                         "note": "FP32 VALU bound (no HBM or MFMA roofline applies: scene is KBs, nothing is a contraction); see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(scene, rays_per_step)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
