@@ -234,6 +234,9 @@ int rt_quantize_device(rt_ctx* ctx, const void* d_rgba, void* d_rgba8, float gai
  * (refraction re, im, dispersion, cos, wavelength); out = kr per record. */
 int rt_kat_intersect(rt_ctx* ctx, const uint32_t* object_index, const float* rays, uint32_t n, float* out);
 int rt_kat_fresnel(rt_ctx* ctx, const float* records, uint32_t n, float* out);
+/* Raw counter words of the last counters-enabled launch, incl. the wave-scheduler diagnostics
+ * (developer tool; returns the number of words). */
+int rt_debug_counters(rt_ctx* ctx, uint64_t* out, uint32_t cap);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB_PATH = os.path.join(_HERE, "libraytracer_host.so")
-HIP_LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+HIP_LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")   # override = developer A/B builds
 
 RT_ABI_VERSION = 1
 RT_OBJ_SPHERE, RT_OBJ_TRIANGLE, RT_OBJ_JULIA = 0, 1, 2
@@ -243,6 +243,12 @@ def hip_lib():
     if _hip is None:
         if not os.path.exists(HIP_LIB_PATH):
             raise RtError("librt_hip.so is not built: run `make hip` (no CPU fallback exists)")
+        try:
+            # torch bundles its own libamdhip64: load it first so the process holds ONE HIP runtime
+            # (librt_hip.so then binds to it; two runtimes in one process cannot both see the GPU)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(HIP_LIB_PATH)
         lib.rt_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
         lib.rt_destroy.argtypes = [C.c_void_p]

@@ -681,6 +681,17 @@ int rt_quantize_device(rt_ctx* ctx, const void* d_rgba, void* d_rgba8, float gai
     return RT_OK;
 }
 
+// Scheduler diagnostics of the last counters-enabled launch: out[i] = raw counter word i (layout:
+// rtd::CounterSlot in rt_scene_dev.h).  Developer tool (tools/gpu_check.py --debug).
+int rt_debug_counters(rt_ctx* ctx, uint64_t* out, uint32_t cap) {
+    if (ctx == nullptr || out == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    unsigned long long c[C_COUNT];
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RT_HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < cap && i < C_COUNT; i++) out[i] = c[i];
+    return C_COUNT;
+}
+
 // ---- known-answer hooks (tests only; declared in include/rt_hip.h under "test hooks") ----------------
 
 // Object::intersect (reference src/objects.h:124-126) of scene object object_index[i] for n rays given

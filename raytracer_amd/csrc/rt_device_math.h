@@ -53,12 +53,23 @@ RT_DEV V3 normalized(V3 v) {
     return {v.x / len, v.y / len, v.z / len};
 }
 
-// src/types.h:188-202, m = row-major 3x4
-RT_DEV V3 xform_point(const float* __restrict__ m, V3 p) {
+// Pointers into the scene tables that are read at wave-uniform addresses are converted to the
+// constant address space: the data is immutable during a launch, so the loads become scalar loads
+// into SGPRs (the tables themselves live in ordinary HBM allocations).
+#define RT_CONSTANT __attribute__((address_space(4)))
+template <typename T>
+RT_DEV const RT_CONSTANT T* to_constant(const T* p) {
+    return (const RT_CONSTANT T*)p;   // NOLINT: address-space cast needs the C form
+}
+
+// src/types.h:188-202, m = row-major 3x4 (any address space)
+template <typename M>
+RT_DEV V3 xform_point(M m, V3 p) {
     return {p.x * m[0] + p.y * m[1] + p.z * m[2] + m[3], p.x * m[4] + p.y * m[5] + p.z * m[6] + m[7],
             p.x * m[8] + p.y * m[9] + p.z * m[10] + m[11]};
 }
-RT_DEV V3 xform_dir(const float* __restrict__ m, V3 p) {
+template <typename M>
+RT_DEV V3 xform_dir(M m, V3 p) {
     return {p.x * m[0] + p.y * m[1] + p.z * m[2], p.x * m[4] + p.y * m[5] + p.z * m[6],
             p.x * m[8] + p.y * m[9] + p.z * m[10]};
 }

@@ -15,12 +15,19 @@ struct HitRec {
 
 // ---- Möller–Trumbore without determinant epsilon or culling (src/objects.cpp:52-81) -------------
 // Returns true with (u, v, t) when the reference would go on to build an Intersection.
-RT_DEV bool tri_test(const DevTriTest& t, V3 o, V3 d, float maxd, float& u, float& v, float& dist) {
-    const V3 e1 = v3(t.e1[0], t.e1[1], t.e1[2]);
-    const V3 e2 = v3(t.e2[0], t.e2[1], t.e2[2]);
+struct TriGeom {
+    V3 p0, e1, e2;
+};
+template <typename P>
+RT_DEV TriGeom load_tri(P t) {
+    return {v3(t->p0[0], t->p0[1], t->p0[2]), v3(t->e1[0], t->e1[1], t->e1[2]), v3(t->e2[0], t->e2[1], t->e2[2])};
+}
+RT_DEV bool tri_test(const TriGeom& t, V3 o, V3 d, float maxd, float& u, float& v, float& dist) {
+    const V3 e1 = t.e1;
+    const V3 e2 = t.e2;
     const V3 h = cross(d, e2);
     const float a = dot(e1, h);
-    const V3 s = o - v3(t.p0[0], t.p0[1], t.p0[2]);
+    const V3 s = o - t.p0;
     u = dot(s, h) / a;
     if (u < -kEpsilon || u > 1.0f) return false;
     const V3 q = cross(s, e1);
@@ -43,15 +50,16 @@ RT_DEV void tri_finish(const DevTriShade& s, V3 o, V3 d, float u, float v, float
 }
 
 // ---- Sphere::intersect (src/objects.cpp:9-50) --------------------------------------------------
-RT_DEV bool sphere_intersect(const DevSphere& s, V3 o_w, V3 d_w, float maxd, HitRec& h) {
-    const V3 o = xform_point(s.w2o, o_w);
-    const V3 d = normalized(xform_dir(s.w2o, d_w));
+template <typename P>
+RT_DEV bool sphere_intersect(P s, V3 o_w, V3 d_w, float maxd, HitRec& h) {
+    const V3 o = xform_point(s->w2o, o_w);
+    const V3 d = normalized(xform_dir(s->w2o, d_w));
     float object_max = kInfinite;
-    if (maxd != kInfinite) object_max = length(o - xform_point(s.w2o, o_w + d_w * maxd));
-    const V3 center = v3(s.center[0], s.center[1], s.center[2]);
+    if (maxd != kInfinite) object_max = length(o - xform_point(s->w2o, o_w + d_w * maxd));
+    const V3 center = v3(s->center[0], s->center[1], s->center[2]);
     const V3 vc = o - center;
     const float b = dot(vc, d);
-    const float c = dot(vc, vc) - s.radius * s.radius;
+    const float c = dot(vc, vc) - s->radius * s->radius;
     const float disc = b * b - c;
     if (disc < 0.0f) return false;
     float t = root_minus(b, disc);
@@ -63,10 +71,10 @@ RT_DEV bool sphere_intersect(const DevSphere& s, V3 o_w, V3 d_w, float maxd, Hit
     const V3 p = o + d * t;
     const V3 n = normalized(p - center);
     const V2 uv = {0.5f + atan2f(n.x, n.z) / (2.0f * kPi), 0.5f - asinf(n.y) / kPi};
-    const V3 pw = xform_point(s.o2w, p);
+    const V3 pw = xform_point(s->o2w, p);
     h.dist = length(o_w - pw);
     h.point = pw;
-    h.normal = normalized(xform_point(s.o2wn, n));
+    h.normal = normalized(xform_point(s->o2wn, n));
     h.uv = uv;
     h.ph = uv;
     return true;

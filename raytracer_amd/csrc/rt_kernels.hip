@@ -25,6 +25,17 @@
 
 namespace rtd {
 
+// register budget of the trace kernel: waves per SIMD the compiler must leave room for
+#ifndef RT_TRACE_WAVES_PER_SIMD
+#define RT_TRACE_WAVES_PER_SIMD 3   // measured on C2/C3: 3 beats 2 (occupancy) and 4 (spills)
+#endif
+#ifndef RT_SERVICE_THRESHOLD
+#define RT_SERVICE_THRESHOLD 16   // lanes waiting outside the march before it is interrupted
+#endif
+#ifndef RT_TRACE_WAVES_JULIA
+#define RT_TRACE_WAVES_JULIA 2
+#endif
+
 enum QueryKind : int { Q_TRACE = 0, Q_SHADOW = 1, Q_PHOTON = 2 };
 enum LaneState : int { S_IDLE = 0, S_QUERY = 1, S_MARCH = 2, S_NORMAL = 3, S_RESOLVE = 4 };
 
@@ -41,10 +52,12 @@ struct Lane {
     V3 qo, qd;
     float qmax;
     int qkind;
-    bool qactive;    // still testing objects (false once a shadow ray is blocked)
-    bool blocked;
+    // flags are kept as 32-bit lane values (VGPRs): as bools they become SGPR lane masks that the
+    // object loop has to re-merge with three scalar instructions each per iteration
+    unsigned qactive;    // still testing objects (0 once a shadow ray is blocked)
+    unsigned blocked;
     // best accepted hit of the current query
-    bool found;
+    unsigned found;
     HitRec best;
     unsigned best_obj;
     float best_cos;
@@ -75,8 +88,8 @@ RT_DEV void bump(Counters& n, int slot, unsigned long long by = 1) {
 RT_DEV void accept_hit(Lane& L, const HitRec& h, unsigned obj, float transmittance, float refr_norm) {
     if (L.qkind == Q_SHADOW) {
         if (dot(L.qd, h.normal) < 0.0f) {   // only front faces cast shadows
-            L.blocked = true;
-            L.qactive = false;
+            L.blocked = 1u;
+            L.qactive = 0u;
         }
         return;
     }
@@ -85,7 +98,7 @@ RT_DEV void accept_hit(Lane& L, const HitRec& h, unsigned obj, float transmittan
         cosv = clampf(dot(L.qd, h.normal), -1.0f, 1.0f);
         if (cosv >= 0.0f && (transmittance == 0.0f || refr_norm == 0.0f)) return;   // unseen back face
     }
-    L.found = true;
+    L.found = 1u;
     L.best = h;
     L.best_obj = obj;
     L.best_cos = cosv;
@@ -97,36 +110,45 @@ RT_DEV void accept_hit(Lane& L, const HitRec& h, unsigned obj, float transmittan
 // addresses.
 template <bool STATS>
 RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, Counters& n) {
-    bool active = in_phase && L.qactive;
+    unsigned act = in_phase ? L.qactive : 0u;   // 32-bit lane value on purpose (see Lane)
+    const auto runs = to_constant(sc.runs);
+    const auto tris = to_constant(sc.tri_test);
+    const auto spheres = to_constant(sc.spheres);
+    const auto obj_mat = to_constant(sc.object_material);
+    const auto mats = to_constant(sc.materials);
     for (unsigned r = 0; r < sc.n_runs; r++) {
-        const DevRun run = sc.runs[r];
-        if (run.kind == RUN_TRIANGLES) {
-            for (unsigned i = 0; i < run.count; i++) {
-                if (!__any(active)) break;
-                const DevTriTest& tt = sc.tri_test[run.first_prim + i];
-                if (active) {
+        const int kind = runs[r].kind;
+        const unsigned first_object = runs[r].first_object, first_prim = runs[r].first_prim, count = runs[r].count;
+        if (kind == RUN_TRIANGLES) {
+            // software-pipelined record fetch: triangle i+1 is on its way to SGPRs while i is tested
+            TriGeom cur = load_tri(tris + first_prim);
+            for (unsigned i = 0; i < count; i++) {
+                if (!__any(act != 0u)) break;
+                const unsigned ahead = i + 1 < count ? i + 1 : i;
+                const TriGeom next = load_tri(tris + first_prim + ahead);
+                if (act != 0u) {
                     bump<STATS>(n, C_TRIANGLE_TESTS);
                     float u, v, t;
-                    if (tri_test(tt, L.qo, L.qd, L.qmax, u, v, t)) {
+                    if (tri_test(cur, L.qo, L.qd, L.qmax, u, v, t)) {
                         HitRec h;
-                        tri_finish(sc.tri_shade[run.first_prim + i], L.qo, L.qd, u, v, t, h);
-                        const DevMaterial& m = sc.materials[sc.object_material[run.first_object + i]];
-                        accept_hit(L, h, run.first_object + i, m.transmittance, m.refr_norm);
-                        active = L.qactive;
+                        tri_finish(sc.tri_shade[first_prim + i], L.qo, L.qd, u, v, t, h);
+                        const unsigned m = obj_mat[first_object + i];
+                        accept_hit(L, h, first_object + i, mats[m].transmittance, mats[m].refr_norm);
+                        act = L.qactive;
                     }
                 }
+                cur = next;
             }
-        } else if (run.kind == RUN_SPHERES) {
-            for (unsigned i = 0; i < run.count; i++) {
-                if (!__any(active)) break;
-                const DevSphere& s = sc.spheres[run.first_prim + i];
-                if (active) {
+        } else if (kind == RUN_SPHERES) {
+            for (unsigned i = 0; i < count; i++) {
+                if (!__any(act != 0u)) break;
+                if (act != 0u) {
                     bump<STATS>(n, C_SPHERE_TESTS);
                     HitRec h;
-                    if (sphere_intersect(s, L.qo, L.qd, L.qmax, h)) {
-                        const DevMaterial& m = sc.materials[sc.object_material[run.first_object + i]];
-                        accept_hit(L, h, run.first_object + i, m.transmittance, m.refr_norm);
-                        active = L.qactive;
+                    if (sphere_intersect(spheres + first_prim + i, L.qo, L.qd, L.qmax, h)) {
+                        const unsigned m = obj_mat[first_object + i];
+                        accept_hit(L, h, first_object + i, mats[m].transmittance, mats[m].refr_norm);
+                        act = L.qactive;
                     }
                 }
             }
@@ -144,14 +166,30 @@ RT_DEV void accept_julia_hit(Lane& L, const HitRec& h, const DevJulia& j, const 
     accept_hit(L, h, j.object, m.transmittance, m.refr_norm);
 }
 
+// Finds the next Julia set (index >= from) whose bounding sphere the current query ray enters and
+// puts the lane into the march state for it; without one the query is complete.
+template <bool STATS>
+RT_DEV void enter_next_julia(const DevScene& sc, Lane& L, unsigned from, Counters& n) {
+    L.state = S_RESOLVE;
+    for (unsigned k = from; k < sc.n_julias; k++) {
+        bump<STATS>(n, C_JULIA_QUERIES);
+        if (julia_enter(sc.julias[k], L.qo, L.qd, L.jp, L.jd)) {
+            L.jidx = k;
+            L.jstep = 0;
+            L.state = S_MARCH;
+            break;
+        }
+    }
+}
+
 RT_DEV void begin_query(Lane& L, V3 o, V3 d, float maxd, int kind) {
     L.qo = o;
     L.qd = d;
     L.qmax = maxd;
     L.qkind = kind;
-    L.qactive = true;
-    L.blocked = false;
-    L.found = false;
+    L.qactive = 1u;
+    L.blocked = 0u;
+    L.found = 0u;
     L.state = S_QUERY;
 }
 
@@ -415,7 +453,7 @@ RT_DEV void flush_counters(const Counters& n, unsigned long long* out) {
 
 // ---- the render kernel ------------------------------------------------------------------------------
 template <bool HAS_JULIA, bool STATS>
-__global__ __launch_bounds__(256) void trace_kernel(const DevScene sc, const DevJob job) {
+__global__ __launch_bounds__(256, HAS_JULIA ? RT_TRACE_WAVES_JULIA : RT_TRACE_WAVES_PER_SIMD) void trace_kernel(const DevScene sc, const DevJob job) {
     Counters n;
     if (STATS) for (int i = 0; i < C_COUNT; i++) n.v[i] = 0;
     const unsigned long long grid_lanes = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
@@ -439,11 +477,15 @@ __global__ __launch_bounds__(256) void trace_kernel(const DevScene sc, const Dev
             const int n_normal = __popcll(__ballot(L.state == S_NORMAL));
             const int n_resolve = __popcll(__ballot(L.state == S_RESOLVE));
             if (n_query + n_march + n_normal + n_resolve == 0) break;
+            // Marching is ~90 % of the work, so keep the march phases full: as soon as enough lanes
+            // wait in the cheap phases they are serviced (largest group first) and rejoin the march.
             phase = S_MARCH;
-            int best = n_march;
-            if (n_normal > best) { best = n_normal; phase = S_NORMAL; }
-            if (n_resolve > best) { best = n_resolve; phase = S_RESOLVE; }
-            if (n_query > best) { best = n_query; phase = S_QUERY; }
+            if (n_march == 0 || n_query + n_normal + n_resolve >= RT_SERVICE_THRESHOLD) {
+                int best = -1;
+                if (n_normal > best && n_normal > 0) { best = n_normal; phase = S_NORMAL; }
+                if (n_resolve > best && n_resolve > 0) { best = n_resolve; phase = S_RESOLVE; }
+                if (n_query > best && n_query > 0) { best = n_query; phase = S_QUERY; }
+            }
         } else {
             // without Julia sets every lane alternates query -> resolve in lockstep
             const bool any_query = __any(L.state == S_QUERY);
@@ -452,39 +494,39 @@ __global__ __launch_bounds__(256) void trace_kernel(const DevScene sc, const Dev
             phase = any_query ? S_QUERY : S_RESOLVE;
         }
 
+        long long t_phase = 0;
+        if (STATS) {
+            t_phase = clock64();
+            const int base = phase == S_QUERY ? D_QUERY_PHASES : phase == S_MARCH ? D_MARCH_PHASES : phase == S_NORMAL ? D_NORMAL_PHASES : D_RESOLVE_PHASES;
+            if ((threadIdx.x & 63) == 0) n.v[base]++;
+            if (L.state == phase) n.v[base + 1]++;
+        }
         if (phase == S_QUERY) {
             const bool mine = L.state == S_QUERY;
             query_objects<STATS>(sc, L, mine, n);
             if (mine) {
-                if (HAS_JULIA && sc.n_julias > 0 && L.qactive) {
-                    L.jidx = 0;
-                    L.state = S_MARCH;
-                    L.jstep = 0xffffffffu;   // not entered yet
-                } else {
-                    L.state = S_RESOLVE;
-                }
+                L.state = S_RESOLVE;
+                if (HAS_JULIA && L.qactive) enter_next_julia<STATS>(sc, L, 0, n);
             }
         } else if (HAS_JULIA && phase == S_MARCH) {
+            unsigned long long my_iters = 0;
             if (L.state == S_MARCH) {
                 const DevJulia& j = sc.julias[L.jidx];
-                bool next_object = false;
-                if (L.jstep == 0xffffffffu) {
-                    bump<STATS>(n, C_JULIA_QUERIES);
-                    if (julia_enter(j, L.qo, L.qd, L.jp, L.jd)) L.jstep = 0; else next_object = true;
+                bump<STATS>(n, C_JULIA_STEPS);
+                unsigned long long iters = 0;
+                const int r = julia_step<STATS>(j, L.jp, L.jd, L.jstep, iters);
+                bump<STATS>(n, C_JULIA_DE_ITERATIONS, iters);
+                my_iters = iters;
+                if (r == 1) L.state = S_NORMAL;
+                if (r == 2) enter_next_julia<STATS>(sc, L, L.jidx + 1, n);
+            }
+            if (STATS) {
+                unsigned long long wmax = my_iters;
+                for (int off = 32; off > 0; off >>= 1) {
+                    const unsigned long long o = __shfl_xor(wmax, off);
+                    wmax = o > wmax ? o : wmax;
                 }
-                if (!next_object) {
-                    bump<STATS>(n, C_JULIA_STEPS);
-                    unsigned long long iters = 0;
-                    const int r = julia_step<STATS>(j, L.jp, L.jd, L.jstep, iters);
-                    bump<STATS>(n, C_JULIA_DE_ITERATIONS, iters);
-                    if (r == 1) L.state = S_NORMAL;
-                    if (r == 2) next_object = true;
-                }
-                if (next_object) {
-                    L.jidx++;
-                    L.jstep = 0xffffffffu;
-                    if (L.jidx >= sc.n_julias) L.state = S_RESOLVE;
-                }
+                if ((threadIdx.x & 63) == 0) n.v[D_DE_WAVE_ITERS] += wmax * 64ull;
             }
         } else if (HAS_JULIA && phase == S_NORMAL) {
             if (L.state == S_NORMAL) {
@@ -496,9 +538,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const DevScene sc, const Dev
                 const float limit = L.qkind == Q_SHADOW ? L.qmax : kInfinite;
                 if (julia_finish<STATS>(j, L.qo, L.jp, L.jd, limit, h, iters)) accept_julia_hit(L, h, j, sc.materials[j.material]);
                 bump<STATS>(n, C_JULIA_DE_ITERATIONS, iters);
-                L.jidx++;
-                L.jstep = 0xffffffffu;
-                L.state = (L.jidx >= sc.n_julias || !L.qactive) ? S_RESOLVE : S_MARCH;
+                if (L.qactive) enter_next_julia<STATS>(sc, L, L.jidx + 1, n); else L.state = S_RESOLVE;
             }
         } else {   // S_RESOLVE
             const bool mine = L.state == S_RESOLVE;
@@ -521,6 +561,10 @@ __global__ __launch_bounds__(256) void trace_kernel(const DevScene sc, const Dev
                     }
                 }
             }
+        }
+        if (STATS && (threadIdx.x & 63) == 0) {
+            const int slot = phase == S_QUERY ? D_QUERY_CYCLES : phase == S_MARCH ? D_MARCH_CYCLES : phase == S_NORMAL ? D_NORMAL_CYCLES : D_RESOLVE_CYCLES;
+            n.v[slot] += static_cast<unsigned long long>(clock64() - t_phase);
         }
     }
     flush_counters<STATS>(n, job.counters);
@@ -679,10 +723,10 @@ __global__ void kat_intersect_kernel(const DevScene sc, const unsigned* __restri
     HitRec h = {};
     bool hit = false;
     if (kind[i] == 0) {
-        hit = sphere_intersect(sc.spheres[prim[i]], o, d, maxd, h);
+        hit = sphere_intersect(sc.spheres + prim[i], o, d, maxd, h);
     } else if (kind[i] == 1) {
         float u, v, t;
-        if (tri_test(sc.tri_test[prim[i]], o, d, maxd, u, v, t)) {
+        if (tri_test(load_tri(sc.tri_test + prim[i]), o, d, maxd, u, v, t)) {
             tri_finish(sc.tri_shade[prim[i]], o, d, u, v, t, h);
             hit = true;
         }

@@ -148,7 +148,12 @@ struct DevPhotonJob {
 enum CounterSlot : int {
     C_PRIMARY = 0, C_SECONDARY, C_SHADOW, C_PHOTON_SEGMENTS, C_PHOTON_DEPOSITS, C_SPHERE_TESTS, C_TRIANGLE_TESTS,
     C_JULIA_QUERIES, C_JULIA_STEPS, C_JULIA_DE_ITERATIONS, C_JULIA_NORMALS, C_SHADED_HITS, C_PHONG_LIGHTS,
-    C_FRESNEL, C_TEXTURE_LOOKUPS, C_BVH_NODE_VISITS, C_COUNT
+    C_FRESNEL, C_TEXTURE_LOOKUPS, C_BVH_NODE_VISITS,
+    // scheduler diagnostics (rt_debug_counters; not part of rt_stats)
+    D_QUERY_PHASES, D_QUERY_LANES, D_MARCH_PHASES, D_MARCH_LANES, D_NORMAL_PHASES, D_NORMAL_LANES,
+    D_RESOLVE_PHASES, D_RESOLVE_LANES, D_DE_WAVE_ITERS,
+    D_QUERY_CYCLES, D_MARCH_CYCLES, D_NORMAL_CYCLES, D_RESOLVE_CYCLES,
+    C_COUNT
 };
 
 }  // namespace rtd

@@ -44,6 +44,21 @@ def main():
               sc.desc.camera.supersampling, pst.kernel_ms, ["%.3f" % t for t in times]), flush=True)
         if args.stats:
             print("  hip stats", {k: v for k, v in st.as_dict().items() if v}, flush=True)
+            import ctypes as C
+            words = (C.c_uint64 * 64)()
+            nw = capi.hip_lib().rt_debug_counters(ctx._ctx, words, 64)
+            names = ["query_phases", "query_lanes", "march_phases", "march_lanes", "normal_phases", "normal_lanes",
+                     "resolve_phases", "resolve_lanes", "de_wave_iter_slots", "query_cycles", "march_cycles",
+                     "normal_cycles", "resolve_cycles"]
+            dbg = dict(zip(names, list(words)[16:nw]))
+            print("  scheduler", dbg, flush=True)
+            for ph in ("query", "march", "normal", "resolve"):
+                if dbg[ph + "_phases"]:
+                    print("   %s: lanes/phase %.1f, cycles/phase %.0f, share of cycles %.1f%%" % (
+                        ph, dbg[ph + "_lanes"] / dbg[ph + "_phases"], dbg[ph + "_cycles"] / dbg[ph + "_phases"],
+                        100.0 * dbg[ph + "_cycles"] / max(1, sum(dbg[q + "_cycles"] for q in ("query", "march", "normal", "resolve")))), flush=True)
+            if dbg["de_wave_iter_slots"]:
+                print("   DE lane-iterations / wave slots = %.3f" % (st.julia_de_iterations / dbg["de_wave_iter_slots"]), flush=True)
         if args.save:
             capi.png_write(args.save, capi.quantize(img))
         if not args.no_oracle:
