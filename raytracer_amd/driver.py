@@ -1,0 +1,234 @@
+"""Multi-GPU render driver: the reference's four render loops (src/main.cpp:14-158), sharded.
+
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
+the CPU tests).  There is no exchange during compute: the only collective is the gather
+of finished pictures to rank 0, which alone accumulates motion blur (in sub-frame order, so the
+rounding is the reference's Picture::mulAdd order) and writes the PNG/APNG.
+
+  stills                 8-row bands of the image, interleaved over the ranks (per-pixel cost is very
+                         uneven on Julia scenes; the reference hands out single rows dynamically,
+                         src/raytracer.cpp:48-53)
+  still + motion blur    sub-frames round-robin over the ranks
+  animation              frames round-robin over the ranks, RGBA8 frames gathered
+  animation + blur       (frame, sub-frame) pairs round-robin over the ranks
+
+The renderer is injected: HipRenderer (below) is the product path; the CPU tests inject a stand-in so
+that the sharding and gather logic can be checked without a GPU.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi
+
+BAND_ROWS = 8
+
+
+class HipRenderer:
+    """Renders through the C ABI on one GPU; pictures stay in HBM as torch tensors."""
+
+    def __init__(self, device_index=0):
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        self.ctx = capi.Context(device_index)
+
+    def render(self, scene, bands=None):
+        self.ctx.upload(scene)
+        stream = torch.cuda.current_stream().cuda_stream
+        if scene.desc.photon_steps > 0:
+            self.ctx.photon_generate_device(stream)
+        n = self.ctx.pixel_count(bands)
+        out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+        if n:
+            self.ctx.render_device(out.data_ptr(), stream, bands)
+        return out
+
+    def mul_add(self, acc, src, factor):
+        self.ctx.mul_add_device(acc.data_ptr(), src.data_ptr(), factor, acc.numel(), torch.cuda.current_stream().cuda_stream)
+
+    def quantize(self, rgba):
+        out = torch.empty(rgba.shape, dtype=torch.uint8, device=rgba.device)
+        self.ctx.quantize_device(rgba.data_ptr(), out.data_ptr(), 1.0, rgba.numel() // 4, torch.cuda.current_stream().cuda_stream)
+        return out
+
+
+def world_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def gather_to_root(tensor):
+    """Returns the list of every rank's tensor on rank 0 (None elsewhere).  Equal shapes required."""
+    rank, world = world_info()
+    if world == 1:
+        return [tensor]
+    out = [torch.empty_like(tensor) for _ in range(world)] if rank == 0 else None
+    dist.gather(tensor, out, dst=0)
+    return out
+
+
+# ---------------------------------------------------------------------------------- schedules
+
+def band_rows_of(height, first_band, stride, band_rows=BAND_ROWS):
+    """Image rows rendered by rt_bands{band_rows, first_band, stride}, in output order."""
+    rows = []
+    for band in range(first_band, (height + band_rows - 1) // band_rows, stride):
+        rows.extend(range(band * band_rows, min(height, (band + 1) * band_rows)))
+    return rows
+
+
+def f32(x):
+    return np.float32(x)
+
+
+def still_time(info):
+    return f32(0.0) if info.still_time == f32(capi.FLT_MAX) else f32(info.still_time)
+
+
+def motion_blur_units(path, info, load=capi.Scene):
+    """[(frame, sub, t, weight, k)] exactly as the reference's loops produce them, including a
+    sub-frame count that the scene file animates (applied from the next frame,
+    src/main.cpp:125-151).  Needs only the host loader."""
+    units = []
+    frames = info.frames
+    k = info.sub_frames
+    if frames > 1 and info.still_time == f32(capi.FLT_MAX):
+        for frame in range(frames):
+            next_k = k
+            for sub in range(k):
+                t = (f32(frame) + f32(sub) / f32(k - 1)) / f32(frames)
+                units.append((frame, sub, float(t), float(f32(1.0) / f32(k)), k))
+                next_k = load(path, float(t)).info.sub_frames
+            k = next_k
+    else:
+        start = still_time(info)
+        k = load(path, float(start)).info.sub_frames
+        for sub in range(k):
+            t = f32(sub) / f32(k - 1) / f32(frames) + start
+            units.append((0, sub, float(t), float(f32(1.0) / f32(k)), k))
+    return units
+
+
+# ---------------------------------------------------------------------------------- the loops
+
+def render_still(renderer, scene):
+    """One picture, bands interleaved over the ranks; returns the full [H,W,4] float picture on rank 0."""
+    rank, world = world_info()
+    h, w = scene.height, scene.width
+    bands = capi.Bands(BAND_ROWS, rank, world)
+    part = renderer.render(scene, bands)
+    # pad to the largest share so that the gather has equal shapes
+    n_max = max(len(band_rows_of(h, r, world)) for r in range(world)) * w
+    padded = torch.zeros((n_max, 4), dtype=part.dtype, device=part.device)
+    padded[: part.shape[0]] = part
+    parts = gather_to_root(padded)
+    if rank != 0:
+        return None
+    full = torch.empty((h, w, 4), dtype=part.dtype, device=part.device)
+    for r in range(world):
+        rows = band_rows_of(h, r, world)
+        if rows:
+            full[torch.as_tensor(rows, device=part.device)] = parts[r][: len(rows) * w].reshape(len(rows), w, 4)
+    return full
+
+
+def render_units(renderer, path, units, consume):
+    """Renders `units` [(key..., t, ...)] round-robin over the ranks, one gather per round; on rank 0
+    calls consume(unit, picture) in unit order."""
+    rank, world = world_info()
+    rounds = math.ceil(len(units) / world)
+    shape = None
+    for i in range(rounds):
+        mine = i * world + rank
+        pic = None
+        if mine < len(units):
+            scene = capi.Scene(path, units[mine][2])
+            pic = renderer.render(scene)
+            shape = pic.shape
+        if pic is None:
+            # a rank without a unit in the last round still takes part in the gather
+            probe = capi.Scene(path, units[0][2])
+            pic = torch.zeros((probe.width * probe.height, 4), dtype=torch.float32,
+                              device=getattr(renderer, "device", torch.device("cpu")))
+        pics = gather_to_root(pic)
+        if rank == 0:
+            for r in range(world):
+                j = i * world + r
+                if j < len(units):
+                    consume(units[j], pics[r])
+    return shape
+
+
+def render_scene_file(renderer, path, out_path=None):
+    """≙ main() of the reference: picks one of the four loops from the scene's settings and writes
+    the PNG/APNG on rank 0.  Returns the list of RGBA8 frames on rank 0 (None elsewhere)."""
+    rank, world = world_info()
+    probe = capi.Scene(path, 0.0)
+    info = probe.info
+    cam = probe.desc.camera
+    if cam.supersampling <= 1 and cam.lens_size != 0.0:
+        raise RuntimeError("Depth of field needs supersampling.")
+    out_path = out_path or info.output_file.decode()
+    h, w = probe.height, probe.width
+    animated = info.frames > 1 and info.still_time == f32(capi.FLT_MAX)
+    frames8 = []
+
+    def to_host8(rgba):
+        q = renderer.quantize(rgba.reshape(h, w, 4).contiguous())
+        return q.cpu().numpy()
+
+    if not animated and info.sub_frames <= 1:
+        scene = capi.Scene(path, float(still_time(info)))
+        full = render_still(renderer, scene)
+        if rank == 0:
+            frames8.append(to_host8(full))
+    elif info.sub_frames <= 1:
+        units = [(f, 0, float(f32(f) / f32(info.frames - 1))) for f in range(info.frames)]
+        render_units(renderer, path, units, lambda u, pic: frames8.append(to_host8(pic)))
+    else:
+        units = motion_blur_units(path, info)
+        state = {"acc": None, "frame": 0}
+
+        def consume(u, pic):
+            frame, sub, _t, weight, k = u
+            if state["acc"] is None:
+                state["acc"] = torch.zeros_like(pic)
+            renderer.mul_add(state["acc"], pic, weight)      # Picture::mulAdd, in sub-frame order
+            if sub == k - 1:
+                frames8.append(to_host8(state["acc"]))
+                state["acc"] = None
+
+        render_units(renderer, path, units, consume)
+    if rank != 0:
+        return None
+    if animated:
+        capi.apng_write(out_path, frames8, info.fps)
+    else:
+        capi.png_write(out_path, frames8[0])
+    return frames8
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description="rt_amd-compatible renderer on 1..N GPUs (launch with torchrun for N > 1)")
+    ap.add_argument("scene")
+    ap.add_argument("out", nargs="?")
+    args = ap.parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    try:
+        render_scene_file(HipRenderer(local_rank), args.scene, args.out)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,107 @@
+"""The multi-rank driver (raytracer_amd/driver.py) on CPU: world_size 2 over gloo.
+
+The renderer is a stand-in that computes with the oracle, so what is under test is the sharding
+(interleaved bands, frames, (frame, sub-frame) pairs), the gather to rank 0, the motion-blur
+accumulation order and the writer — the gathered result must equal the single-process result
+bit for bit.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from conftest import ROOT, scene_path
+from raytracer_amd import capi, driver
+
+ASSETS2 = os.path.join(ROOT, "scenes", "examples2")
+
+
+def small_scene(tmp_path, extra_scene_tags="", camera_pos='x="0;1.5(b)" y="0;1(b)" z="-2;-3(b)"', size=(40, 28), steps=60):
+    xml = tmp_path / "s.xml"
+    xml.write_text('''<scene output_file="%s">
+  <background_color r="0.0" g="0.0" b="0.0"/>%s
+  <caustic steps="%d" texture_size="24" factor="0.5"/>
+  <camera><position %s/><lookat x="0" y="0" z="-6.5"/><up x="0" y="1" z="0"/>
+    <horizontal_fov angle="45"/><resolution horizontal="%d" vertical="%d"/><max_bounces n="4"/></camera>
+  <lights><ambient_light><color r="1" g="1" b="1"/></ambient_light>
+    <point_light><color r="0.7" g="0.7" b="0.7"/><position x="2" y="3" z="-2.5"/></point_light></lights>
+  <surfaces>
+    <mesh name="%s/open_room.obj"><material_solid><color r="0.6" g="0.6" b="0.6"/><phong ka="0.3" kd="0.9" ks="1.0" exponent="20"/>
+      <reflectance r="0"/><transmittance t="0"/><refraction iof="0"/></material_solid></mesh>
+    <mesh name="%s/box2.obj"><material_solid><color r="0.17" g="0.18" b="0.5"/><phong ka="0" kd="0" ks="0" exponent="200"/>
+      <reflectance r="0.8"/><transmittance t="0.8"/><refraction iof="1.5168" ec="9.7525e-9" disp="-0.2"/></material_solid></mesh>
+  </surfaces></scene>''' % (tmp_path / "out.png", extra_scene_tags, steps, camera_pos, size[0], size[1], ASSETS2, ASSETS2))
+    return str(xml)
+
+
+def run_two_ranks(scene, tmp_path):
+    out, result = str(tmp_path / "dist.png"), str(tmp_path / "dist.npy")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", os.path.join(ROOT, "tests", "dist_worker.py"), scene, out, result]
+    subprocess.run(cmd, check=True, env=env, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    return np.load(result), out
+
+
+def single_process_frames(scene):
+    """The four loops run sequentially in this process with the oracle (the reference's order)."""
+    probe = capi.Scene(scene, 0.0)
+    info = probe.info
+    h, w = probe.height, probe.width
+
+    def picture(t):
+        sc = capi.Scene(scene, float(t))
+        ph = oracle_lib.Photons(sc) if sc.desc.photon_steps > 0 else None
+        return oracle_lib.render(sc, ph, threads=4)[0]
+    animated = info.frames > 1 and info.still_time == np.float32(capi.FLT_MAX)
+    if info.sub_frames <= 1:
+        times = [np.float32(f) / np.float32(info.frames - 1) for f in range(info.frames)] if animated else [driver.still_time(info)]
+        return [capi.quantize(picture(t)) for t in times]
+    frames, acc = [], None
+    for frame, sub, t, weight, k in driver.motion_blur_units(scene, info):
+        if acc is None:
+            acc = np.zeros((h, w, 4), dtype=np.float32)
+        acc += picture(t) * np.float32(weight)
+        if sub == k - 1:
+            frames.append(capi.quantize(acc))
+            acc = None
+    return frames
+
+
+@pytest.mark.parametrize("kind,tags", [
+    ("still", ""),
+    ("animation", '<animation length="0.5" fps="6"/>'),
+    ("still_blur", '<motionblur subframes="3"/>'),
+    ("animation_blur", '<animation length="0.4" fps="5"/><motionblur subframes="2;4"/>'),
+])
+def test_two_ranks_equal_one(tmp_path, kind, tags):
+    scene = small_scene(tmp_path, tags)
+    got, png = run_two_ranks(scene, tmp_path)
+    want = single_process_frames(scene)
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    # what rank 0 wrote decodes to the same frames
+    for i, b in enumerate(want):
+        img, n = capi.png_read(png, i)
+        assert n == len(want) and np.array_equal(img, b)
+
+
+def test_schedules():
+    # interleaved bands cover every row exactly once, whatever the world size
+    for h in (1, 7, 8, 600, 2160):
+        for world in (1, 2, 3, 8):
+            rows = sorted(y for r in range(world) for y in driver.band_rows_of(h, r, world))
+            assert rows == list(range(h))
+    # frame/sub-frame times of the shipped animation variant (reference src/main.cpp:140)
+    path = scene_path("examples3/103_caustic_animation_mb8.xml")
+    info = capi.Scene(path, 0.0).info
+    units = driver.motion_blur_units(path, info)
+    assert len(units) == 20 * 8
+    f, s, t, wgt, k = units[8 * 3 + 5]
+    assert (f, s, k) == (3, 5, 8)
+    assert t == float((np.float32(3) + np.float32(5) / np.float32(7)) / np.float32(20))
+    assert wgt == float(np.float32(1) / np.float32(8))
