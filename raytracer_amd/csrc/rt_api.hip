@@ -27,6 +27,7 @@ __global__ void kat_fresnel_kernel(const float* in, unsigned n, float* out);
 __global__ void mul_add_kernel(float* acc, const float* src, float factor, unsigned long long n);
 __global__ void quantize_kernel(const float4* rgba, uchar4* out, float gain, unsigned long long n);
 constexpr int kFrameFieldsHost = 11;
+constexpr size_t kMaxLdsBlobBytes = 36 * 1024;   // keeps 4 blocks per CU within the 160 KB LDS
 }  // namespace rtd
 
 using namespace rtd;
@@ -137,9 +138,9 @@ void make_job(const rt_ctx* ctx, const rt_bands* bands, DevJob* job) {
 }
 
 template <typename K>
-int persistent_grid(rt_ctx* ctx, K kernel, uint64_t work_items, int* blocks) {
+int persistent_grid(rt_ctx* ctx, K kernel, uint64_t work_items, int* blocks, size_t lds_bytes = 0) {
     int per_cu = 0;
-    RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0));
+    RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes));
     if (per_cu < 1) per_cu = 1;
     uint64_t g = static_cast<uint64_t>(ctx->n_cus) * per_cu;
     const uint64_t needed = (work_items + 255) / 256;
@@ -159,8 +160,9 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     const bool stats = ctx->collect_stats;
     int blocks = 0;
     int rc;
-    if (julia) rc = stats ? persistent_grid(ctx, trace_kernel<true, true>, job.n_samples, &blocks) : persistent_grid(ctx, trace_kernel<true, false>, job.n_samples, &blocks);
-    else rc = stats ? persistent_grid(ctx, trace_kernel<false, true>, job.n_samples, &blocks) : persistent_grid(ctx, trace_kernel<false, false>, job.n_samples, &blocks);
+    const size_t lds = ctx->dev.shade_blob_in_lds ? ctx->dev.shade_blob_bytes : 0;
+    if (julia) rc = stats ? persistent_grid(ctx, trace_kernel<true, true>, job.n_samples, &blocks, lds) : persistent_grid(ctx, trace_kernel<true, false>, job.n_samples, &blocks, lds);
+    else rc = stats ? persistent_grid(ctx, trace_kernel<false, true>, job.n_samples, &blocks, lds) : persistent_grid(ctx, trace_kernel<false, false>, job.n_samples, &blocks, lds);
     if (rc != RT_OK) return rc;
     const uint64_t lanes = static_cast<uint64_t>(blocks) * 256;
     rc = grow(ctx, ctx->stack, lanes * (ctx->dev.max_bounces + 1) * kFrameFieldsHost * sizeof(float));
@@ -178,11 +180,11 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long), stream));
     RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
     if (julia) {
-        if (stats) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, ctx->dev, job);
-        else hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, ctx->dev, job);
+        if (stats) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
+        else hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
     } else {
-        if (stats) hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, ctx->dev, job);
-        else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, ctx->dev, job);
+        if (stats) hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
+        else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
     }
     RT_HIP_TRY(ctx, hipGetLastError());
     if (job.samples_per_pixel > 1) {
@@ -423,7 +425,6 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
         if (lights[i].type == 1) ctx->point_lights.push_back(i);
     }
     sc.n_lights = d->n_lights;
-    if ((rc = upload(ctx, lights, &sc.lights)) != RT_OK) return rc;
 
     // ---- materials, textures -----------------------------------------------------------------------
     std::vector<DevMaterial> mats(d->n_materials);
@@ -438,7 +439,6 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
         o.refr_norm = m.refraction_re * m.refraction_re + m.refraction_im * m.refraction_im;   // std::norm
         o.pad = 0.0f;
     }
-    if ((rc = upload(ctx, mats, &sc.materials)) != RT_OK) return rc;
     std::vector<DevTexture> texs(d->n_textures);
     std::vector<float4> texels;
     for (uint32_t i = 0; i < d->n_textures; i++) {
@@ -452,7 +452,6 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
         }
     }
     if (texels.size() > 0xffffffffull) return fail(ctx, RT_ERR_LIMIT, "texture pool too large");
-    if ((rc = upload(ctx, texs, &sc.textures)) != RT_OK) return rc;
     if ((rc = upload(ctx, texels, &sc.texels)) != RT_OK) return rc;
 
     // ---- geometry ----------------------------------------------------------------------------------
@@ -547,11 +546,36 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
     sc.n_julias = static_cast<uint32_t>(julias.size());
     if ((rc = upload(ctx, runs, &sc.runs)) != RT_OK) return rc;
     if ((rc = upload(ctx, tt_ord, &sc.tri_test)) != RT_OK) return rc;
-    if ((rc = upload(ctx, ts_ord, &sc.tri_shade)) != RT_OK) return rc;
     if ((rc = upload(ctx, spheres_ord, &sc.spheres)) != RT_OK) return rc;
     if ((rc = upload(ctx, julias, &sc.julias)) != RT_OK) return rc;
-    if ((rc = upload(ctx, obj_material, &sc.object_material)) != RT_OK) return rc;
-    if ((rc = upload(ctx, ctx->photon_slot, &sc.object_photon_slot)) != RT_OK) return rc;
+    {
+        // the shade blob: every table the shading code reads per lane, 16-byte aligned pieces
+        std::vector<unsigned char> blob;
+        auto place = [&blob](const void* data, size_t bytes) -> size_t {
+            const size_t off = (blob.size() + 15) & ~size_t(15);
+            blob.resize(off + (bytes ? bytes : 16), 0);
+            if (bytes) std::memcpy(blob.data() + off, data, bytes);
+            return off;
+        };
+        const size_t o_mat = place(mats.data(), mats.size() * sizeof(DevMaterial));
+        const size_t o_light = place(lights.data(), lights.size() * sizeof(DevLight));
+        const size_t o_tex = place(texs.data(), texs.size() * sizeof(DevTexture));
+        const size_t o_om = place(obj_material.data(), obj_material.size() * sizeof(uint32_t));
+        const size_t o_ps = place(ctx->photon_slot.data(), ctx->photon_slot.size() * sizeof(int32_t));
+        const size_t o_ts = place(ts_ord.data(), ts_ord.size() * sizeof(DevTriShade));
+        blob.resize((blob.size() + 15) & ~size_t(15), 0);
+        const unsigned char* d_blob = nullptr;
+        if ((rc = upload(ctx, blob, &d_blob)) != RT_OK) return rc;
+        sc.shade_blob = d_blob;
+        sc.shade_blob_bytes = static_cast<uint32_t>(blob.size());
+        sc.shade_blob_in_lds = blob.size() <= kMaxLdsBlobBytes ? 1u : 0u;
+        sc.materials = reinterpret_cast<const DevMaterial*>(d_blob + o_mat);
+        sc.lights = reinterpret_cast<const DevLight*>(d_blob + o_light);
+        sc.textures = reinterpret_cast<const DevTexture*>(d_blob + o_tex);
+        sc.object_material = reinterpret_cast<const uint32_t*>(d_blob + o_om);
+        sc.object_photon_slot = reinterpret_cast<const int32_t*>(d_blob + o_ps);
+        sc.tri_shade = reinterpret_cast<const DevTriShade*>(d_blob + o_ts);
+    }
     sc.bvh_nodes = nullptr;
     sc.bvh_prims = nullptr;
 

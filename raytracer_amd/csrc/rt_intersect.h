@@ -38,13 +38,65 @@ RT_DEV bool tri_test(const TriGeom& t, V3 o, V3 d, float maxd, float& u, float& 
     return true;
 }
 
+// The test above split for instruction-level parallelism.  Stage 1 (edge cross product, determinant,
+// first barycentric numerator) is straight-line code without division, so several triangles can be
+// in flight per lane; it also decides most rejections exactly, without the division:
+//   u = fl(nu/a) > 1          <=>  m > |a|              (m = nu with the sign of a folded in)
+//   m*3333 < -|a|              =>  u < -3e-4 < -EPSILON
+// (proofs in DESIGN.md §4; a == 0, infinities and NaNs fall through to the exact stage).  Survivors
+// run the reference's own sequence in tri_stage23.
+struct TriStage1 {
+    V3 s;
+    float a, nu;
+    bool maybe;
+};
+RT_DEV TriStage1 tri_stage1(const TriGeom& t, V3 o, V3 d) {
+    TriStage1 r;
+    const V3 h = cross(d, t.e2);
+    r.a = dot(t.e1, h);
+    r.s = o - t.p0;
+    r.nu = dot(r.s, h);
+    const float m = r.a < 0.0f ? -r.nu : r.nu;
+    const float aa = fabsf(r.a);
+    r.maybe = !(m > aa || m * 3333.0f < -aa);
+    return r;
+}
+RT_DEV bool tri_stage23(const TriGeom& t, const TriStage1& r, V3 d, float maxd, float& u, float& v, float& dist) {
+    u = r.nu / r.a;
+    if (u < -kEpsilon || u > 1.0f) return false;
+    const V3 q = cross(r.s, t.e1);
+    v = dot(d, q) / r.a;
+    if (v < -kEpsilon || u + v > 1.0f) return false;
+    dist = dot(t.e2, q) / r.a;
+    if (dist < 0 || dist > maxd) return false;
+    return true;
+}
+
+// Interpolated (not yet normalised) vertex normal, the argument of normalized() in src/objects.cpp:86-90
+template <typename P>
+RT_DEV V3 tri_normal_sum(P s, float u, float v) {
+    const float w = 1.0f - (u + v);
+    return v3(s->n0[0], s->n0[1], s->n0[2]) * w + v3(s->n1[0], s->n1[1], s->n1[2]) * u + v3(s->n2[0], s->n2[1], s->n2[2]) * v;
+}
+
+// dot(d, normalized(nv)) where only its sign is needed (back-face rule, shadow rule): when the
+// unnormalised dot product is clear of zero by 10x the worst-case rounding error of both evaluations
+// the sign is returned as +-1 without the normalisation; otherwise the reference's expression is
+// evaluated.  (|d| = 1; error bounds in DESIGN.md §4.)
+RT_DEV float facing(V3 d, V3 nv) {
+    const float c = dot(d, nv);
+    const float bound = 1e-5f * (fabsf(nv.x) + fabsf(nv.y) + fabsf(nv.z));
+    if (c > bound) return 1.0f;
+    if (c < -bound) return -1.0f;
+    return dot(d, normalized(nv));
+}
+
 // Rest of Triangle::intersect (src/objects.cpp:83-98)
 RT_DEV void tri_finish(const DevTriShade& s, V3 o, V3 d, float u, float v, float dist, HitRec& h) {
     const float w = 1.0f - (u + v);
     h.dist = dist;
     h.point = o + d * dist;
-    h.normal = normalized(v3(s.n0[0], s.n0[1], s.n0[2]) * w + v3(s.n1[0], s.n1[1], s.n1[2]) * u +
-                          v3(s.n2[0], s.n2[1], s.n2[2]) * v);
+    h.normal = normalized(tri_normal_sum(&s, u, v));
     h.uv = {s.uv0[0] * w + s.uv1[0] * u + s.uv2[0] * v, s.uv0[1] * w + s.uv1[1] * u + s.uv2[1] * v};
     h.ph = {w, u};
 }

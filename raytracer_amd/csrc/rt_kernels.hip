@@ -29,6 +29,9 @@ namespace rtd {
 #ifndef RT_TRACE_WAVES_PER_SIMD
 #define RT_TRACE_WAVES_PER_SIMD 3   // measured on C2/C3: 3 beats 2 (occupancy) and 4 (spills)
 #endif
+#ifndef RT_TRI_GROUP
+#define RT_TRI_GROUP 4
+#endif
 #ifndef RT_SERVICE_THRESHOLD
 #define RT_SERVICE_THRESHOLD 16   // lanes waiting outside the march before it is interrupted
 #endif
@@ -40,10 +43,33 @@ enum QueryKind : int { Q_TRACE = 0, Q_SHADOW = 1, Q_PHOTON = 2 };
 enum LaneState : int { S_IDLE = 0, S_QUERY = 1, S_MARCH = 2, S_NORMAL = 3, S_RESOLVE = 4 };
 
 constexpr int kFrameFields = 11;
+constexpr unsigned kNoTriangle = 0xffffffffu;
 
 struct Counters {
     unsigned long long v[C_COUNT];
 };
+
+// The tables the shading code reads per lane (HBM, or their LDS copy for small scenes).
+struct ShadeTables {
+    const DevMaterial* materials;
+    const DevLight* lights;
+    const DevTexture* textures;
+    const uint32_t* object_material;
+    const int32_t* object_photon_slot;
+    const DevTriShade* tri_shade;
+};
+RT_DEV ShadeTables tables_of(const DevScene& sc, const unsigned char* base) {
+    // base == sc.shade_blob leaves the pointers where they are; an LDS base rebases them
+    const unsigned char* g = sc.shade_blob;
+    ShadeTables t;
+    t.materials = reinterpret_cast<const DevMaterial*>(base + (reinterpret_cast<const unsigned char*>(sc.materials) - g));
+    t.lights = reinterpret_cast<const DevLight*>(base + (reinterpret_cast<const unsigned char*>(sc.lights) - g));
+    t.textures = reinterpret_cast<const DevTexture*>(base + (reinterpret_cast<const unsigned char*>(sc.textures) - g));
+    t.object_material = reinterpret_cast<const uint32_t*>(base + (reinterpret_cast<const unsigned char*>(sc.object_material) - g));
+    t.object_photon_slot = reinterpret_cast<const int32_t*>(base + (reinterpret_cast<const unsigned char*>(sc.object_photon_slot) - g));
+    t.tri_shade = reinterpret_cast<const DevTriShade*>(base + (reinterpret_cast<const unsigned char*>(sc.tri_shade) - g));
+    return t;
+}
 
 // Everything one lane carries between phases.
 struct Lane {
@@ -61,6 +87,10 @@ struct Lane {
     HitRec best;
     unsigned best_obj;
     float best_cos;
+    // a winning triangle is kept as (triangle, u, v, distance) until the query is over; its full hit
+    // record is built once by finish_best_triangle
+    unsigned best_tri;
+    float best_u, best_v;
     // Julia march
     unsigned jidx, jstep;
     V3 jp, jd;
@@ -71,6 +101,9 @@ struct Lane {
     unsigned n_obj;
     float acc[3], matcol[3];
     unsigned li;
+    // the newest frame of the DFS stack is kept in registers; HBM only holds the frames below it
+    // (written when a deeper frame is pushed, prefetched back when the top is popped)
+    float top[11];
     // sample
     unsigned sp;             // frames on the stack == depth of the current node
     float wavelength;
@@ -102,7 +135,38 @@ RT_DEV void accept_hit(Lane& L, const HitRec& h, unsigned obj, float transmittan
     L.best = h;
     L.best_obj = obj;
     L.best_cos = cosv;
+    L.best_tri = kNoTriangle;
     L.qmax = h.dist;
+}
+
+// The same rule for a triangle candidate (u, v, dist) whose interpolated normal sum is nv; only the
+// facing decision is taken here, the hit record is deferred.
+RT_DEV void accept_triangle(Lane& L, unsigned obj, unsigned tri, float u, float v, float dist, V3 nv, float transmittance, float refr_norm) {
+    if (L.qkind == Q_SHADOW) {
+        if (facing(L.qd, nv) < 0.0f) {
+            L.blocked = 1u;
+            L.qactive = 0u;
+        }
+        return;
+    }
+    if (L.qkind == Q_TRACE && (transmittance == 0.0f || refr_norm == 0.0f) && facing(L.qd, nv) >= 0.0f) return;
+    L.found = 1u;
+    L.best_obj = obj;
+    L.best_tri = tri;
+    L.best_u = u;
+    L.best_v = v;
+    L.best.dist = dist;
+    L.qmax = dist;
+}
+
+// Completes a deferred triangle winner (rest of Triangle::intersect and the cosine of
+// src/raytracer.cpp:131).
+RT_DEV void finish_best_triangle(const ShadeTables& T, Lane& L) {
+    if (L.found != 0u && L.best_tri != kNoTriangle) {
+        tri_finish(T.tri_shade[L.best_tri], L.qo, L.qd, L.best_u, L.best_v, L.best.dist, L.best);
+        L.best_cos = L.qkind == Q_TRACE ? clampf(dot(L.qd, L.best.normal), -1.0f, 1.0f) : 0.0f;
+        L.best_tri = kNoTriangle;
+    }
 }
 
 // The wave-uniform object loop: every lane with L.qactive tests its ray against every non-Julia
@@ -113,31 +177,53 @@ RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, Counters& 
     unsigned act = in_phase ? L.qactive : 0u;   // 32-bit lane value on purpose (see Lane)
     const auto runs = to_constant(sc.runs);
     const auto tris = to_constant(sc.tri_test);
+    const auto shades = to_constant(sc.tri_shade);
     const auto spheres = to_constant(sc.spheres);
     const auto obj_mat = to_constant(sc.object_material);
     const auto mats = to_constant(sc.materials);
     for (unsigned r = 0; r < sc.n_runs; r++) {
         const int kind = runs[r].kind;
         const unsigned first_object = runs[r].first_object, first_prim = runs[r].first_prim, count = runs[r].count;
+        const long long t_run = STATS ? clock64() : 0;
         if (kind == RUN_TRIANGLES) {
-            // software-pipelined record fetch: triangle i+1 is on its way to SGPRs while i is tested
-            TriGeom cur = load_tri(tris + first_prim);
-            for (unsigned i = 0; i < count; i++) {
+            // RT_TRI_GROUP triangles per trip: their records arrive in SGPRs together and their
+            // division-free first stages are independent instruction streams; the (rare) survivors
+            // are finished one after the other in scene order against the running maximum.
+            for (unsigned i = 0; i < count; i += RT_TRI_GROUP) {
                 if (!__any(act != 0u)) break;
-                const unsigned ahead = i + 1 < count ? i + 1 : i;
-                const TriGeom next = load_tri(tris + first_prim + ahead);
-                if (act != 0u) {
-                    bump<STATS>(n, C_TRIANGLE_TESTS);
-                    float u, v, t;
-                    if (tri_test(cur, L.qo, L.qd, L.qmax, u, v, t)) {
-                        HitRec h;
-                        tri_finish(sc.tri_shade[first_prim + i], L.qo, L.qd, u, v, t, h);
-                        const unsigned m = obj_mat[first_object + i];
-                        accept_hit(L, h, first_object + i, mats[m].transmittance, mats[m].refr_norm);
-                        act = L.qactive;
+                TriGeom g[RT_TRI_GROUP];
+                TriStage1 s1[RT_TRI_GROUP];
+#pragma unroll
+                for (int k = 0; k < RT_TRI_GROUP; k++) {
+                    const unsigned idx = i + k < count ? i + k : count - 1;
+                    g[k] = load_tri(tris + first_prim + idx);
+                }
+                bool any_maybe = false;
+#pragma unroll
+                for (int k = 0; k < RT_TRI_GROUP; k++) {
+                    s1[k] = tri_stage1(g[k], L.qo, L.qd);
+                    any_maybe = any_maybe || (s1[k].maybe && i + k < count);
+                }
+                if (STATS) {
+                    // the oracle's count: tests made while the query is still open (a shadow ray stops
+                    // at its first blocker), in order
+                    if (act != 0u && !any_maybe) bump<STATS>(n, C_TRIANGLE_TESTS, count - i < RT_TRI_GROUP ? count - i : RT_TRI_GROUP);
+                }
+                if (act != 0u && any_maybe) {
+#pragma unroll
+                    for (int k = 0; k < RT_TRI_GROUP; k++) {
+                        if (i + k < count && act != 0u) {
+                            bump<STATS>(n, C_TRIANGLE_TESTS);
+                            float u, v, t;
+                            if (s1[k].maybe && tri_stage23(g[k], s1[k], L.qd, L.qmax, u, v, t)) {
+                                const V3 nv = tri_normal_sum(shades + first_prim + i + k, u, v);
+                                const unsigned m = obj_mat[first_object + i + k];
+                                accept_triangle(L, first_object + i + k, first_prim + i + k, u, v, t, nv, mats[m].transmittance, mats[m].refr_norm);
+                                act = L.qactive;
+                            }
+                        }
                     }
                 }
-                cur = next;
             }
         } else if (kind == RUN_SPHERES) {
             for (unsigned i = 0; i < count; i++) {
@@ -153,6 +239,7 @@ RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, Counters& 
                 }
             }
         }
+        if (STATS && (threadIdx.x & 63) == 0) n.v[kind == RUN_TRIANGLES ? D_TRI_CYCLES : D_SPHERE_CYCLES] += static_cast<unsigned long long>(clock64() - t_run);
     }
 }
 
@@ -190,6 +277,7 @@ RT_DEV void begin_query(Lane& L, V3 o, V3 d, float maxd, int kind) {
     L.qactive = 1u;
     L.blocked = 0u;
     L.found = 0u;
+    L.best_tri = kNoTriangle;
     L.state = S_QUERY;
 }
 
@@ -275,8 +363,8 @@ RT_DEV void store_sample(const DevScene& sc, const DevJob& job, const Lane& L, C
 }
 
 // Shadow query towards light L.li from the current node (src/raytracer.cpp:214-220).
-RT_DEV void begin_shadow(const DevScene& sc, Lane& L) {
-    const DevLight& light = sc.lights[L.li];
+RT_DEV void begin_shadow(const ShadeTables& T, Lane& L) {
+    const DevLight& light = T.lights[L.li];
     const V3 lpos = v3(light.position[0], light.position[1], light.position[2]);
     const V3 dir = normalized(light.type == 0 ? lpos * -1.0f : lpos - L.n_point);
     const V3 origin = L.n_point + L.n_normal * kEpsilon;
@@ -284,16 +372,30 @@ RT_DEV void begin_shadow(const DevScene& sc, Lane& L) {
     begin_query(L, origin, dir, ldist, Q_SHADOW);
 }
 
+// Section timer of the counters build: the first active lane of the wave charges the cycles since
+// the previous mark to `slot`.
+template <bool STATS>
+RT_DEV void mark(Counters& n, long long& t, int slot) {
+    if (STATS) {
+        const long long now = clock64();
+        const unsigned long long m = __ballot(1);
+        if ((threadIdx.x & 63) == static_cast<unsigned>(__ffsll(static_cast<long long>(m)) - 1)) n.v[slot] += static_cast<unsigned long long>(now - t);
+        t = now;
+    }
+}
+
 // ---- resolve phase: advance one lane's ray tree by one query result ---------------------------------
 template <bool STATS>
-RT_DEV void resolve_lane(const DevScene& sc, const DevJob& job, const FrameRef& stack, Lane& L, Counters& n,
+RT_DEV void resolve_lane(const DevScene& sc, const ShadeTables& T, const DevJob& job, const FrameRef& stack, Lane& L, Counters& n,
                          bool& sample_done, Col& sample_value) {
     bool lights_done = false;
     bool returning = false;
     float val[3] = {0.0f, 0.0f, 0.0f};
     float val_a = 0.0f;
+    long long t_sec = STATS ? clock64() : 0;
 
     if (L.qkind == Q_TRACE) {
+        finish_best_triangle(T, L);
         bump<STATS>(n, L.sp == 0 ? C_PRIMARY : C_SECONDARY);
         if (!L.found) {
             val[0] = sc.background[0];
@@ -312,11 +414,11 @@ RT_DEV void resolve_lane(const DevScene& sc, const DevJob& job, const FrameRef& 
             L.acc[0] = L.acc[1] = L.acc[2] = 0.0f;
             L.li = 0;
             if (L.n_cos < 0.0f) {
-                const DevMaterial& m = sc.materials[sc.object_material[L.n_obj]];
+                const DevMaterial& m = T.materials[T.object_material[L.n_obj]];
                 Col mc = {m.color[0], m.color[1], m.color[2], m.color[3]};
                 if (m.texture >= 0) {
                     bump<STATS>(n, C_TEXTURE_LOOKUPS);
-                    mc = texture_bilinear(sc.textures[m.texture], sc.texels, L.best.uv);
+                    mc = texture_bilinear(T.textures[m.texture], sc.texels, L.best.uv);
                 }
                 L.matcol[0] = mc.r;
                 L.matcol[1] = mc.g;
@@ -333,8 +435,8 @@ RT_DEV void resolve_lane(const DevScene& sc, const DevJob& job, const FrameRef& 
         bump<STATS>(n, C_SHADOW);
         bump<STATS>(n, C_PHONG_LIGHTS);
         if (!L.blocked) {
-            const DevMaterial& m = sc.materials[sc.object_material[L.n_obj]];
-            const DevLight& light = sc.lights[L.li];
+            const DevMaterial& m = T.materials[T.object_material[L.n_obj]];
+            const DevLight& light = T.lights[L.li];
             const float ndotl = dot(L.qd, L.n_normal);
             const float lambert = ndotl < 0.0f ? 0.0f : ndotl;   // std::max(x, 0.0f)
             const V3 refl = normalized(L.n_normal * ndotl * 2.0f - L.qd);
@@ -350,13 +452,15 @@ RT_DEV void resolve_lane(const DevScene& sc, const DevJob& job, const FrameRef& 
         L.li++;
     }
 
+    mark<STATS>(n, t_sec, L.qkind == Q_TRACE ? D_R_NODE_CYCLES : D_R_LIGHT_CYCLES);
     if (!returning && !lights_done) {
         if (L.li < sc.n_lights) {
-            begin_shadow(sc, L);
+            begin_shadow(T, L);
+            mark<STATS>(n, t_sec, D_R_SHADOWSETUP_CYCLES);
             return;
         }
         // rad += object.getPhoton(photonCoordinate)   (src/raytracer.cpp:146)
-        const int slot = sc.object_photon_slot[L.n_obj];
+        const int slot = T.object_photon_slot[L.n_obj];
         if (slot >= 0 && sc.photon_atlas != nullptr) {
             const unsigned texel = photon_texel(L.n_ph, sc.photon_size);
             const float4 ph = sc.photon_atlas[static_cast<size_t>(slot) * sc.photon_size * sc.photon_size + texel];
@@ -369,7 +473,7 @@ RT_DEV void resolve_lane(const DevScene& sc, const DevJob& job, const FrameRef& 
 
     if (!returning) {
         // Fresnel split (src/raytracer.cpp:151-159)
-        const DevMaterial& m = sc.materials[sc.object_material[L.n_obj]];
+        const DevMaterial& m = T.materials[T.object_material[L.n_obj]];
         bool descended = false;
         if ((m.transmittance != 0.0f || m.reflectance != 0.0f) && m.refr_norm > 0.0f) {
             bump<STATS>(n, C_FRESNEL);
@@ -383,26 +487,29 @@ RT_DEV void resolve_lane(const DevScene& sc, const DevJob& job, const FrameRef& 
                 if (want_refl) reflection_ray(L.n_dir, L.n_point, L.n_normal, L.n_cos, mo, md);
                 if (refr_ok || want_refl) {
                     const unsigned f = L.sp;
-                    stack.at(f, 0) = L.acc[0];
-                    stack.at(f, 1) = L.acc[1];
-                    stack.at(f, 2) = L.acc[2];
-                    stack.at(f, 3) = kr;
-                    if (refr_ok && want_refl) {
-                        stack.at(f, 4) = mo.x;
-                        stack.at(f, 5) = mo.y;
-                        stack.at(f, 6) = mo.z;
-                        stack.at(f, 7) = md.x;
-                        stack.at(f, 8) = md.y;
-                        stack.at(f, 9) = md.z;
+                    if (f > 0) {
+#pragma unroll
+                        for (int c = 0; c < kFrameFields; c++) stack.at(f - 1, c) = L.top[c];   // spill the old top
                     }
+                    L.top[0] = L.acc[0];
+                    L.top[1] = L.acc[1];
+                    L.top[2] = L.acc[2];
+                    L.top[3] = kr;
+                    L.top[4] = mo.x;
+                    L.top[5] = mo.y;
+                    L.top[6] = mo.z;
+                    L.top[7] = md.x;
+                    L.top[8] = md.y;
+                    L.top[9] = md.z;
                     // flags: bit0 = the child now in flight is the reflection, bit1 = reflection still to do
-                    stack.at(f, 10) = __uint_as_float(refr_ok ? (want_refl ? 2u : 0u) : 1u);
+                    L.top[10] = __uint_as_float(refr_ok ? (want_refl ? 2u : 0u) : 1u);
                     L.sp = f + 1;
                     if (refr_ok) begin_query(L, ro, rd, kInfinite, Q_TRACE); else begin_query(L, mo, md, kInfinite, Q_TRACE);
                     descended = true;
                 }
             }
         }
+        mark<STATS>(n, t_sec, D_R_FRESNEL_CYCLES);
         if (descended) return;
         val[0] = L.acc[0];
         val[1] = L.acc[1];
@@ -416,22 +523,26 @@ RT_DEV void resolve_lane(const DevScene& sc, const DevJob& job, const FrameRef& 
             sample_done = true;
             sample_value = {val[0], val[1], val[2], val_a};
             L.state = S_IDLE;
+            mark<STATS>(n, t_sec, D_R_RETURN_CYCLES);
             return;
         }
         const unsigned f = L.sp - 1;
-        const unsigned flags = __float_as_uint(stack.at(f, 10));
-        const float kr = stack.at(f, 3);
+        const unsigned flags = __float_as_uint(L.top[10]);
+        const float kr = L.top[3];
         const float w = (flags & 1u) ? kr : 1.0f - kr;
         float acc[3];
-        for (int c = 0; c < 3; c++) acc[c] = stack.at(f, c) + val[c] * w;
+        for (int c = 0; c < 3; c++) acc[c] = L.top[c] + val[c] * w;
         if (flags & 2u) {
             // refraction child done, reflection child next
-            for (int c = 0; c < 3; c++) stack.at(f, c) = acc[c];
-            stack.at(f, 10) = __uint_as_float(1u);
-            const V3 mo = v3(stack.at(f, 4), stack.at(f, 5), stack.at(f, 6));
-            const V3 md = v3(stack.at(f, 7), stack.at(f, 8), stack.at(f, 9));
-            begin_query(L, mo, md, kInfinite, Q_TRACE);
+            for (int c = 0; c < 3; c++) L.top[c] = acc[c];
+            L.top[10] = __uint_as_float(1u);
+            begin_query(L, v3(L.top[4], L.top[5], L.top[6]), v3(L.top[7], L.top[8], L.top[9]), kInfinite, Q_TRACE);
+            mark<STATS>(n, t_sec, D_R_RETURN_CYCLES);
             return;
+        }
+        if (f > 0) {
+#pragma unroll
+            for (int c = 0; c < kFrameFields; c++) L.top[c] = stack.at(f - 1, c);   // prefetch the new top
         }
         L.sp = f;
         val[0] = acc[0];
@@ -453,7 +564,21 @@ RT_DEV void flush_counters(const Counters& n, unsigned long long* out) {
 
 // ---- the render kernel ------------------------------------------------------------------------------
 template <bool HAS_JULIA, bool STATS>
-__global__ __launch_bounds__(256, HAS_JULIA ? RT_TRACE_WAVES_JULIA : RT_TRACE_WAVES_PER_SIMD) void trace_kernel(const DevScene sc, const DevJob job) {
+__global__ __launch_bounds__(256, HAS_JULIA ? RT_TRACE_WAVES_JULIA : RT_TRACE_WAVES_PER_SIMD) void trace_kernel(const DevScene sc_global, const DevJob job) {
+    // With a small scene the shading tables are read from an LDS copy of the shade blob (latency
+    // ~64 cycles instead of an L2 round trip per dependent load); the wave-uniform geometry reads
+    // keep using the HBM tables (scalar loads).
+    extern __shared__ __align__(16) unsigned char lds_blob[];
+    const DevScene& sc = sc_global;
+    const unsigned char* table_base = sc.shade_blob;
+    if (sc.shade_blob_in_lds) {
+        for (unsigned i = threadIdx.x * 16u; i < sc.shade_blob_bytes; i += 256u * 16u) {
+            *reinterpret_cast<uint4*>(lds_blob + i) = *reinterpret_cast<const uint4*>(sc.shade_blob + i);
+        }
+        __syncthreads();
+        table_base = lds_blob;
+    }
+    const ShadeTables T = tables_of(sc, table_base);
     Counters n;
     if (STATS) for (int i = 0; i < C_COUNT; i++) n.v[i] = 0;
     const unsigned long long grid_lanes = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
@@ -494,7 +619,7 @@ __global__ __launch_bounds__(256, HAS_JULIA ? RT_TRACE_WAVES_JULIA : RT_TRACE_WA
             phase = any_query ? S_QUERY : S_RESOLVE;
         }
 
-        long long t_phase = 0;
+        long long t_phase = 0, t_fetch_outer = 0;
         if (STATS) {
             t_phase = clock64();
             const int base = phase == S_QUERY ? D_QUERY_PHASES : phase == S_MARCH ? D_MARCH_PHASES : phase == S_NORMAL ? D_NORMAL_PHASES : D_RESOLVE_PHASES;
@@ -536,7 +661,7 @@ __global__ __launch_bounds__(256, HAS_JULIA ? RT_TRACE_WAVES_JULIA : RT_TRACE_WA
                 HitRec h;
                 // Julia::intersect ignores max_distance until this final check (src/objects.cpp:236)
                 const float limit = L.qkind == Q_SHADOW ? L.qmax : kInfinite;
-                if (julia_finish<STATS>(j, L.qo, L.jp, L.jd, limit, h, iters)) accept_julia_hit(L, h, j, sc.materials[j.material]);
+                if (julia_finish<STATS>(j, L.qo, L.jp, L.jd, limit, h, iters)) accept_julia_hit(L, h, j, T.materials[j.material]);
                 bump<STATS>(n, C_JULIA_DE_ITERATIONS, iters);
                 if (L.qactive) enter_next_julia<STATS>(sc, L, L.jidx + 1, n); else L.state = S_RESOLVE;
             }
@@ -544,7 +669,8 @@ __global__ __launch_bounds__(256, HAS_JULIA ? RT_TRACE_WAVES_JULIA : RT_TRACE_WA
             const bool mine = L.state == S_RESOLVE;
             bool done = false;
             Col value = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (mine && !fresh) resolve_lane<STATS>(sc, job, stack, L, n, done, value);
+            if (mine && !fresh) resolve_lane<STATS>(sc, T, job, stack, L, n, done, value);
+            t_fetch_outer = STATS ? clock64() : 0;
             if (mine && done) store_sample(sc, job, L, value);
             bool need = mine && (fresh || done);
             if (need) L.state = S_IDLE;
@@ -562,6 +688,7 @@ __global__ __launch_bounds__(256, HAS_JULIA ? RT_TRACE_WAVES_JULIA : RT_TRACE_WA
                 }
             }
         }
+        if (STATS && phase == S_RESOLVE && (threadIdx.x & 63) == 0) n.v[D_R_FETCH_CYCLES] += static_cast<unsigned long long>(clock64() - t_fetch_outer);
         if (STATS && (threadIdx.x & 63) == 0) {
             const int slot = phase == S_QUERY ? D_QUERY_CYCLES : phase == S_MARCH ? D_MARCH_CYCLES : phase == S_NORMAL ? D_NORMAL_CYCLES : D_RESOLVE_CYCLES;
             n.v[slot] += static_cast<unsigned long long>(clock64() - t_phase);
@@ -597,6 +724,7 @@ __global__ __launch_bounds__(256) void photon_kernel(const DevScene sc, const De
     const unsigned long long gid = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     const FrameRef stack = {job.stack + gid, grid_lanes};
 
+    const ShadeTables T = tables_of(sc, sc.shade_blob);
     Lane L;
     L.state = S_IDLE;
     L.sp = 0;
@@ -617,7 +745,7 @@ __global__ __launch_bounds__(256) void photon_kernel(const DevScene sc, const De
                     q /= job.n_theta;
                     const unsigned pi = static_cast<unsigned>(q % job.n_phi);
                     const unsigned li = static_cast<unsigned>(q / job.n_phi);
-                    const DevLight& light = sc.lights[job.point_lights[li]];
+                    const DevLight& light = T.lights[job.point_lights[li]];
                     const float st = job.sin_theta[ti], ct = job.cos_theta[ti], sp_ = job.sin_phi[pi], cp = job.cos_phi[pi];
                     const V3 dir = normalized(v3(st * cp, st * sp_, ct));
                     if (sc.dispersion) {
@@ -646,17 +774,18 @@ __global__ __launch_bounds__(256) void photon_kernel(const DevScene sc, const De
                     HitRec h;
                     unsigned long long steps = 0, iters = 0;
                     bump<STATS>(n, C_JULIA_QUERIES);
-                    if (julia_intersect_inline<STATS>(j, L.qo, L.qd, kInfinite, h, steps, iters)) accept_julia_hit(L, h, j, sc.materials[j.material]);
+                    if (julia_intersect_inline<STATS>(j, L.qo, L.qd, kInfinite, h, steps, iters)) accept_julia_hit(L, h, j, T.materials[j.material]);
                     bump<STATS>(n, C_JULIA_STEPS, steps);
                     bump<STATS>(n, C_JULIA_DE_ITERATIONS, iters);
                 }
             }
+            finish_best_triangle(T, L);
             bool pop = true;
             if (L.found) {
-                const DevMaterial& m = sc.materials[sc.object_material[L.best_obj]];
+                const DevMaterial& m = T.materials[T.object_material[L.best_obj]];
                 if (m.refr_norm <= 0.0f) {
                     // the light ray ends on a diffuse object (src/photonmap.cpp:79-83)
-                    const int slot = sc.object_photon_slot[L.best_obj];
+                    const int slot = T.object_photon_slot[L.best_obj];
                     if (depth > 0 && slot >= 0) {
                         bump<STATS>(n, C_PHOTON_DEPOSITS);
                         const unsigned texel = photon_texel(L.best.ph, sc.photon_size);

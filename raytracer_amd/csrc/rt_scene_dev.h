@@ -108,6 +108,13 @@ struct DevScene {
     const DevBvhNode* bvh_nodes;
     const uint32_t* bvh_prims;         // triangle indices (into tri_test) in leaf order
 
+    // lights, materials, textures, tri_shade and the two per-object tables live in ONE allocation
+    // ("shade blob"); when it is small enough the trace kernel copies it into LDS and the per-lane
+    // shading reads go there instead of L2 (the pointers above are rebased inside the kernel)
+    const unsigned char* shade_blob;
+    uint32_t shade_blob_bytes;
+    uint32_t shade_blob_in_lds;        // 0/1, decided by the host from the blob size
+
     float4* photon_atlas;              // [n_slots][size][size]
     uint32_t photon_size;
     float photon_factor;
@@ -152,7 +159,8 @@ enum CounterSlot : int {
     // scheduler diagnostics (rt_debug_counters; not part of rt_stats)
     D_QUERY_PHASES, D_QUERY_LANES, D_MARCH_PHASES, D_MARCH_LANES, D_NORMAL_PHASES, D_NORMAL_LANES,
     D_RESOLVE_PHASES, D_RESOLVE_LANES, D_DE_WAVE_ITERS,
-    D_QUERY_CYCLES, D_MARCH_CYCLES, D_NORMAL_CYCLES, D_RESOLVE_CYCLES,
+    D_QUERY_CYCLES, D_MARCH_CYCLES, D_NORMAL_CYCLES, D_RESOLVE_CYCLES, D_TRI_CYCLES, D_SPHERE_CYCLES,
+    D_R_NODE_CYCLES, D_R_LIGHT_CYCLES, D_R_SHADOWSETUP_CYCLES, D_R_FRESNEL_CYCLES, D_R_RETURN_CYCLES, D_R_FETCH_CYCLES,
     C_COUNT
 };
 

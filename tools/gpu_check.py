@@ -49,7 +49,8 @@ def main():
             nw = capi.hip_lib().rt_debug_counters(ctx._ctx, words, 64)
             names = ["query_phases", "query_lanes", "march_phases", "march_lanes", "normal_phases", "normal_lanes",
                      "resolve_phases", "resolve_lanes", "de_wave_iter_slots", "query_cycles", "march_cycles",
-                     "normal_cycles", "resolve_cycles"]
+                     "normal_cycles", "resolve_cycles", "tri_cycles", "sphere_cycles",
+                     "r_node", "r_light", "r_shadowsetup", "r_fresnel", "r_return", "r_fetch"]
             dbg = dict(zip(names, list(words)[16:nw]))
             print("  scheduler", dbg, flush=True)
             for ph in ("query", "march", "normal", "resolve"):
@@ -57,6 +58,11 @@ def main():
                     print("   %s: lanes/phase %.1f, cycles/phase %.0f, share of cycles %.1f%%" % (
                         ph, dbg[ph + "_lanes"] / dbg[ph + "_phases"], dbg[ph + "_cycles"] / dbg[ph + "_phases"],
                         100.0 * dbg[ph + "_cycles"] / max(1, sum(dbg[q + "_cycles"] for q in ("query", "march", "normal", "resolve")))), flush=True)
+            print("   inside query: triangle runs %.1f%%, sphere runs %.1f%% of query cycles" % (
+                100.0 * dbg["tri_cycles"] / max(1, dbg["query_cycles"]), 100.0 * dbg["sphere_cycles"] / max(1, dbg["query_cycles"])), flush=True)
+            rc = max(1, dbg["resolve_cycles"])
+            print("   inside resolve: " + ", ".join("%s %.1f%%" % (k[2:], 100.0 * dbg[k] / rc) for k in
+                  ("r_node", "r_light", "r_shadowsetup", "r_fresnel", "r_return", "r_fetch")), flush=True)
             if dbg["de_wave_iter_slots"]:
                 print("   DE lane-iterations / wave slots = %.3f" % (st.julia_de_iterations / dbg["de_wave_iter_slots"]), flush=True)
         if args.save:
