@@ -38,7 +38,8 @@ WORKLOADS = {
 # cheapest exit).  Transcendentals and the FP64 sub-expressions are not counted.
 FLOPS = {"triangle_tests": 29, "sphere_tests": 59, "shaded_hits": 64, "phong_lights": 75, "fresnel_evals": 110,
          "texture_lookups": 40, "primary_rays": 60, "secondary_rays": 37, "julia_de_iterations": 41,
-         "julia_steps": 11, "julia_normals": 36, "julia_queries": 30, "photon_segments": 37}
+         "julia_steps": 11, "julia_normals": 36, "julia_queries": 30, "photon_segments": 37,
+         "bvh_node_visits": 21}   # ours, not the reference's: slab test of one node (6 sub, 6 mul, 6 min/max, 3 compares)
 PEAK_FP32_TFLOPS = 157.3   # MI355X FP32 vector peak (MI355X_MICROARCH.md)
 
 
@@ -74,7 +75,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["mesh"])
+    ap.add_argument("--bvh-min", type=int, default=None, help="developer: RT_OPT_BVH_MIN_TRIANGLES before the upload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -91,9 +93,19 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
-    rel, t, label = WORKLOADS[args.workload]
-    scene = capi.Scene(os.path.join(ROOT, "scenes", rel), t)
+    if args.workload == "mesh":     # developer workload for the BVH: 104k-triangle synthetic mesh, 1920x1080
+        import pathlib
+        import tempfile
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import mesh_scene
+        rel, t, label = "mesh.xml", 0.0, "synthetic 104k-triangle mesh 1920x1080 (tests/mesh_scene.py)"
+        scene = capi.Scene(mesh_scene.write_mesh_scene(pathlib.Path(tempfile.mkdtemp()), 160, 320, width=1920, height=1080), t)
+    else:
+        rel, t, label = WORKLOADS[args.workload]
+        scene = capi.Scene(os.path.join(ROOT, "scenes", rel), t)
     ctx = capi.Context(local_rank)
+    if args.bvh_min is not None:
+        ctx.set_option(capi.RT_OPT_BVH_MIN_TRIANGLES, args.bvh_min)
     ctx.upload(scene)
     w, h = scene.width, scene.height
     n_pix = w * h

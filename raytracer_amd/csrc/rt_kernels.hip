@@ -169,6 +169,57 @@ RT_DEV void finish_best_triangle(const ShadeTables& T, Lane& L) {
     }
 }
 
+// Per-lane traversal of one run's BVH (built on the GPU by rt_bvh.hip).  Returns the winner the
+// sequential scan of the run would return: nearest accepted hit, equal distances to the later object.
+constexpr unsigned kBvhLeaf = 0xffffffffu;
+template <bool STATS>
+RT_DEV void query_bvh(const DevScene& sc, Lane& L, unsigned act, unsigned bvh_root, unsigned first_object, unsigned first_prim, Counters& n) {
+    if (act == 0u) return;
+    const V3 inv = {1.0f / L.qd.x, 1.0f / L.qd.y, 1.0f / L.qd.z};
+    unsigned stack[64];
+    int sp = 0;
+    unsigned node = 0;
+    for (;;) {
+        bump<STATS>(n, C_BVH_NODE_VISITS);
+        const float4* raw = reinterpret_cast<const float4*>(sc.bvh_nodes + bvh_root + node);
+        const float4 a = raw[0], b = raw[1];   // lo.xyz, a | hi.xyz, b
+        // slab test; fminf/fmaxf drop the NaNs of 0*inf so that an axis-parallel ray lying in a face
+        // plane is kept; the far side is widened by 2 ulp (robust traversal)
+        const float x0 = (a.x - L.qo.x) * inv.x, x1 = (b.x - L.qo.x) * inv.x;
+        const float y0 = (a.y - L.qo.y) * inv.y, y1 = (b.y - L.qo.y) * inv.y;
+        const float z0 = (a.z - L.qo.z) * inv.z, z1 = (b.z - L.qo.z) * inv.z;
+        const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+        const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        const bool overlap = !(tnear > tfar * 1.0000004f) && !(tfar < 0.0f) && !(tnear > L.qmax);
+        const unsigned ia = __float_as_uint(a.w), ib = __float_as_uint(b.w);
+        if (overlap) {
+            if (ib == kBvhLeaf) {
+                bump<STATS>(n, C_TRIANGLE_TESTS);
+                const unsigned tri = ia;
+                const TriGeom g = load_tri(sc.tri_test + tri);
+                const TriStage1 s1 = tri_stage1(g, L.qo, L.qd);
+                float u, v, t;
+                if (s1.maybe && tri_stage23(g, s1, L.qd, L.qmax, u, v, t)) {
+                    const unsigned obj = first_object + (tri - first_prim);
+                    // order-independent form of the scan's tie rule (t <= running maximum, later wins)
+                    if (L.qkind == Q_SHADOW || t < L.qmax || L.found == 0u || obj > L.best_obj) {
+                        const V3 nv = tri_normal_sum(sc.tri_shade + tri, u, v);
+                        const DevMaterial& m = sc.materials[sc.object_material[obj]];
+                        accept_triangle(L, obj, tri, u, v, t, nv, m.transmittance, m.refr_norm);
+                        if (L.qactive == 0u) break;
+                    }
+                }
+            } else {
+                stack[sp++] = ib;
+                node = ia;
+                continue;
+            }
+        }
+        if (sp == 0) break;
+        node = stack[--sp];
+    }
+}
+
 // The wave-uniform object loop: every lane with L.qactive tests its ray against every non-Julia
 // object in scene order.  `runs`, the geometry tables and the material flags are read at uniform
 // addresses.
@@ -225,6 +276,9 @@ RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, Counters& 
                     }
                 }
             }
+        } else if (kind == RUN_TRIANGLE_BVH) {
+            query_bvh<STATS>(sc, L, act, runs[r].bvh_root, first_object, first_prim, n);
+            act = in_phase ? L.qactive : 0u;
         } else if (kind == RUN_SPHERES) {
             for (unsigned i = 0; i < count; i++) {
                 if (!__any(act != 0u)) break;
@@ -239,7 +293,7 @@ RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, Counters& 
                 }
             }
         }
-        if (STATS && (threadIdx.x & 63) == 0) n.v[kind == RUN_TRIANGLES ? D_TRI_CYCLES : D_SPHERE_CYCLES] += static_cast<unsigned long long>(clock64() - t_run);
+        if (STATS && (threadIdx.x & 63) == 0) n.v[kind != RUN_SPHERES ? D_TRI_CYCLES : D_SPHERE_CYCLES] += static_cast<unsigned long long>(clock64() - t_run);
     }
 }
 

@@ -138,6 +138,9 @@ def test_frame_bit_exact_vs_oracle_and_reference_png(hip_ctx, name, rel, t, png,
     # the work counters are the numerator of the roofline: they must be the oracle's
     for k in ("primary_rays", "secondary_rays", "shadow_rays", "sphere_tests", "triangle_tests", "shaded_hits",
               "fresnel_evals", "texture_lookups"):
+        if k == "triangle_tests" and st.bvh_node_visits > 0:
+            assert st.triangle_tests < ost.triangle_tests     # a BVH run (>= 48 triangles) skips most of them
+            continue
         assert getattr(st, k) == getattr(ost, k), k
     gold, _n = capi.png_read(golden_path(png[0]), png[1])
     d = assert_north_star(capi.quantize(img), gold, name)
@@ -337,3 +340,65 @@ def test_depth_of_field_statistically(hip_ctx):
     assert np.array_equal(a, b)                      # deterministic for a seed
     assert not np.array_equal(a, c)                  # and the seed matters
     assert abs(float(a[..., :3].mean()) - float(c[..., :3].mean())) < 0.01
+
+
+# ---- GPU-built BVH ------------------------------------------------------------------------------------
+
+from mesh_scene import write_mesh_scene  # noqa: E402
+
+
+def test_bvh_equals_the_sequential_scan_on_a_large_mesh(tmp_path):
+    """~11k triangles: the GPU-built BVH path against the oracle's brute-force scan, bit for bit, and
+    against our own brute-force kernel (BVH switched off)."""
+    sc = capi.Scene(write_mesh_scene(tmp_path), 0.0)
+    assert sc.desc.n_triangles > 10000
+    ctx = capi.Context(0)
+    ctx.set_option(capi.RT_OPT_COLLECT_STATS, 1)
+    ctx.set_option(capi.RT_OPT_BVH_MIN_TRIANGLES, 64)
+    ctx.upload(sc)
+    img, st = ctx.render()
+    assert st.bvh_node_visits > 0
+    ref, ost = oracle_lib.render(sc, None, threads=16)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert st.triangle_tests < ost.triangle_tests / 20          # the point of the BVH
+    ctx.set_option(capi.RT_OPT_BVH_MIN_TRIANGLES, 1 << 40)
+    ctx.upload(sc)
+    brute, st2 = ctx.render()
+    assert st2.bvh_node_visits == 0 and st2.triangle_tests == ost.triangle_tests
+    assert np.array_equal(brute.view(np.uint32), img.view(np.uint32))
+    ctx.close()
+
+
+def test_zero_area_triangles_keep_the_sequential_scan(tmp_path):
+    """Zero-area triangles make the reference divide by zero (src/objects.cpp:66-78) and accept hits at
+    NaN distance, after which the LAST object hit in scene order wins; only the scan reproduces that,
+    so such a run gets no BVH — and the picture still equals the oracle's, NaNs included."""
+    sc = capi.Scene(write_mesh_scene(tmp_path, 12, 24, poles=True), 0.0)
+    ctx = capi.Context(0)
+    ctx.set_option(capi.RT_OPT_COLLECT_STATS, 1)
+    ctx.set_option(capi.RT_OPT_BVH_MIN_TRIANGLES, 2)
+    ctx.upload(sc)
+    img, st = ctx.render()
+    ref, ost = oracle_lib.render(sc, None, threads=16)
+    assert st.triangle_tests == ost.triangle_tests
+    assert np.array_equal(np.isnan(img), np.isnan(ref))
+    assert np.array_equal(np.nan_to_num(img).view(np.uint32), np.nan_to_num(ref).view(np.uint32))
+    ctx.close()
+
+
+def test_bvh_forced_on_the_configured_scenes():
+    """The same pictures with every triangle run (2 triangles and up) behind a BVH."""
+    ctx = capi.Context(0)
+    ctx.set_option(capi.RT_OPT_BVH_MIN_TRIANGLES, 2)
+    for rel, t in (("examples/example9_lowres.xml", 0.0), ("examples2/8_fresnel.xml", 0.0), ("examples3/103_caustic_steps200.xml", 0.5)):
+        sc = capi.Scene(scene_path(rel), t)
+        ctx.upload(sc)
+        pst = ctx.photon_generate()
+        img, _ = ctx.render()
+        ph = oracle_lib.Photons(sc) if sc.desc.photon_steps > 0 else None
+        ref, _ = oracle_lib.render(sc, ph, threads=16)
+        if ph is None:
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), rel
+        else:
+            assert np.allclose(img, ref, rtol=1e-5, atol=1e-7), rel
+    ctx.close()
