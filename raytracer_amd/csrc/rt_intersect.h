@@ -147,25 +147,33 @@ struct Quat {
 // Julia::estimateDistance (src/objects.cpp:122-135).  The Hamilton square is written term for term
 // as src/types.h:246-253 evaluates z*z.  Exact early-out: once d2 is +inf and m2 stays finite the
 // returned value is (+/-)0 whatever the remaining iterations do.
+// One pass of the loop body; returns true when the loop ends by one of its breaks.
+RT_DEV bool julia_iterate(Quat& z, const Quat& c, float& d2, float& m2) {
+    d2 *= 4.0f * m2;
+    const float nr = z.r * z.r - z.a * z.a - z.b * z.b - z.c * z.c;
+    const float na = z.r * z.a + z.a * z.r + z.b * z.c - z.c * z.b;
+    const float nb = z.r * z.b - z.a * z.c + z.b * z.r + z.c * z.a;
+    const float nc = z.r * z.c + z.a * z.b - z.b * z.a + z.c * z.r;
+    z = {nr + c.r, na + c.a, nb + c.b, nc + c.c};
+    m2 = z.r * z.r + z.a * z.a + z.b * z.b + z.c * z.c;
+    return m2 > 1e10f || d2 == __builtin_inff();
+}
+RT_DEV float julia_norm2(const Quat& z) { return z.r * z.r + z.a * z.a + z.b * z.b + z.c * z.c; }
+// sqrt(m2/d2)*0.5f*log(sqrt(m2)): float division, everything else in double (Y8)
+RT_DEV float julia_distance_tail(float m2, float d2) {
+    const double tail = sqrt(static_cast<double>(m2 / d2)) * 0.5 * log(sqrt(static_cast<double>(m2)));
+    return static_cast<float>(tail);
+}
+
 template <bool COUNT>
 RT_DEV float julia_distance(Quat z, Quat c, unsigned iterations, unsigned long long& n_iter) {
     float d2 = 1.0f;
-    float m2 = z.r * z.r + z.a * z.a + z.b * z.b + z.c * z.c;
+    float m2 = julia_norm2(z);
     for (unsigned i = 0; i < iterations; i++) {
         if (COUNT) n_iter++;
-        d2 *= 4.0f * m2;
-        const float nr = z.r * z.r - z.a * z.a - z.b * z.b - z.c * z.c;
-        const float na = z.r * z.a + z.a * z.r + z.b * z.c - z.c * z.b;
-        const float nb = z.r * z.b - z.a * z.c + z.b * z.r + z.c * z.a;
-        const float nc = z.r * z.c + z.a * z.b - z.b * z.a + z.c * z.r;
-        z = {nr + c.r, na + c.a, nb + c.b, nc + c.c};
-        m2 = z.r * z.r + z.a * z.a + z.b * z.b + z.c * z.c;
-        if (m2 > 1e10f) break;
-        if (d2 == __builtin_inff()) break;
+        if (julia_iterate(z, c, d2, m2)) break;
     }
-    // sqrt(m2/d2)*0.5f*log(sqrt(m2)): float division, everything else in double (Y8)
-    const double tail = sqrt(static_cast<double>(m2 / d2)) * 0.5 * log(sqrt(static_cast<double>(m2)));
-    return static_cast<float>(tail);
+    return julia_distance_tail(m2, d2);
 }
 
 // Julia::estimateNormal (src/objects.cpp:140-160), object space
@@ -217,9 +225,7 @@ RT_DEV bool julia_finish(const DevJulia& j, V3 o_w, V3 p, V3 d, float maxd, HitR
 
 // One march step (src/objects.cpp:206-217).  Returns 0 = keep marching, 1 = converged (hit
 // candidate), 2 = gave up (miss).  `i` is the step index before the call.
-template <bool COUNT>
-RT_DEV int julia_step(const DevJulia& j, V3& p, V3 d, unsigned& i, unsigned long long& n_iter) {
-    float dist = julia_distance<COUNT>({p.x, p.y, p.z, j.cut_plane}, {j.c[0], j.c[1], j.c[2], j.c[3]}, kJuliaDistanceIterations, n_iter);
+RT_DEV int julia_advance(float dist, V3& p, V3 d, unsigned& i) {
     if (i == 0 && dist < kJuliaConvergence) {
         dist = 100 * kJuliaConvergence;
     } else if (dist < kJuliaConvergence || dist > kJuliaDivergence) {
@@ -229,6 +235,11 @@ RT_DEV int julia_step(const DevJulia& j, V3& p, V3 d, unsigned& i, unsigned long
     i++;
     if (i >= kJuliaSearchIterations) return dist >= kJuliaConvergence ? 2 : 1;
     return 0;
+}
+template <bool COUNT>
+RT_DEV int julia_step(const DevJulia& j, V3& p, V3 d, unsigned& i, unsigned long long& n_iter) {
+    const float dist = julia_distance<COUNT>({p.x, p.y, p.z, j.cut_plane}, {j.c[0], j.c[1], j.c[2], j.c[3]}, kJuliaDistanceIterations, n_iter);
+    return julia_advance(dist, p, d, i);
 }
 
 // Whole Julia::intersect in one go (used where no wave-level scheduling is worth it: the
