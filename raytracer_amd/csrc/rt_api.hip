@@ -64,7 +64,7 @@ struct rt_ctx {
     uint32_t* d_point_lights = nullptr;
     // options
     bool collect_stats = false;
-    int64_t bvh_min_triangles = 48;   // measured: 18-20 triangles lose 25 %, 64 win 11 %
+    int64_t bvh_min_triangles = 256;  // below this the chunk-culled scan wins (C2, 64 triangles: 2.9 ms against 3.9 ms with the BVH)
     uint32_t dof_seed = 0;
     // per-call scratch, grown on demand and kept
     Buffer samples, stack, out_staging, kat_a, kat_b, kat_c, kat_d;
@@ -545,9 +545,95 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
     sc.n_objects = d->n_objects;
     sc.n_runs = static_cast<uint32_t>(runs.size());
     sc.n_julias = static_cast<uint32_t>(julias.size());
+    // chunk bounds of the triangle runs (same conservative growth as the BVH leaf boxes in rt_bvh.hip;
+    // a chunk with a degenerate triangle is unbounded: src/objects.cpp:66-78 divides by zero there and
+    // accepts NaN hits for rays that come nowhere near it)
+    std::vector<DevTriChunk> chunks;
+    for (DevRun& r : runs) {
+        if (r.kind != RUN_TRIANGLES) continue;
+        r.first_chunk = static_cast<uint32_t>(chunks.size());
+        for (uint32_t i = 0; i < r.count; i += kTriChunk) {
+            DevTriChunk c{};
+            bool bounded = true;
+            for (int a = 0; a < 3; a++) { c.lo[a] = INFINITY; c.hi[a] = -INFINITY; }
+            for (uint32_t k = i; k < r.count && k < i + kTriChunk; k++) {
+                const DevTriTest& t = tt_ord[r.first_prim + k];
+                const double e1[3] = {t.e1[0], t.e1[1], t.e1[2]}, e2[3] = {t.e2[0], t.e2[1], t.e2[2]};
+                const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+                const double area2 = cx * cx + cy * cy + cz * cz;
+                const double l1 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], l2 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
+                const double p0 = std::fabs(double(t.p0[0])) + std::fabs(double(t.p0[1])) + std::fabs(double(t.p0[2]));
+                if (!(area2 > 1e-12 * l1 * l2) || !std::isfinite(area2) || !std::isfinite(p0)) bounded = false;
+                for (int a = 0; a < 3; a++) {
+                    const float q0 = t.p0[a], q1 = t.p0[a] + t.e1[a], q2 = t.p0[a] + t.e2[a];
+                    const float lo = std::fmin(q0, std::fmin(q1, q2)), hi = std::fmax(q0, std::fmax(q1, q2));
+                    const float grow = 2.0f * 0.0001f * (std::fabs(t.e1[a]) + std::fabs(t.e2[a])) + 4e-6f * std::fmax(std::fabs(lo), std::fabs(hi)) + 1e-30f;
+                    c.lo[a] = std::fmin(c.lo[a], lo - grow);
+                    c.hi[a] = std::fmax(c.hi[a], hi + grow);
+                }
+            }
+            if (!bounded) {
+                for (int a = 0; a < 3; a++) { c.lo[a] = -INFINITY; c.hi[a] = INFINITY; }
+            }
+            chunks.push_back(c);
+        }
+    }
+    if ((rc = upload(ctx, chunks, &sc.tri_chunks)) != RT_OK) return rc;
     if ((rc = upload(ctx, runs, &sc.runs)) != RT_OK) return rc;
     if ((rc = upload(ctx, tt_ord, &sc.tri_test)) != RT_OK) return rc;
     if ((rc = upload(ctx, spheres_ord, &sc.spheres)) != RT_OK) return rc;
+    {
+        // Bounding spheres for the wave-level sphere culling.  A ray is skipped only when, in exact
+        // arithmetic, it misses the bounding sphere by more than every rounding error Sphere::intersect
+        // (src/objects.cpp:12-44) can make: that code works in object space with binary32 operations on
+        // magnitudes up to |W||o| + |t| + |centre| + r, so its discriminant, roots and object-space
+        // maximum are off by at most a few ulps of those magnitudes squared; mapped back to world space
+        // the error grows by the condition number of the transform.  slack = 256 * 2^-24 * cond^2 *
+        // (|o|^2 + magnitude2) covers it with two orders of magnitude to spare; transforms that are not
+        // finite or are singular get an unbounded sphere (never skipped).
+        std::vector<DevSphereBound> sb(spheres_ord.size());
+        for (size_t i = 0; i < spheres_ord.size(); i++) {
+            const DevSphere& s = spheres_ord[i];
+            DevSphereBound& b = sb[i];
+            double a[3][3], cw[3];
+            bool ok = true;
+            for (int r = 0; r < 3; r++) {
+                cw[r] = s.o2w[r * 4 + 3];
+                for (int c = 0; c < 3; c++) {
+                    a[r][c] = s.o2w[r * 4 + c];
+                    cw[r] += a[r][c] * s.center[c];
+                    ok = ok && std::isfinite(a[r][c]) && std::isfinite(double(s.w2o[r * 4 + c]));
+                }
+                ok = ok && std::isfinite(cw[r]) && std::isfinite(double(s.w2o[r * 4 + 3]));
+            }
+            // spectral norms of o2w and w2o (3x3 parts), bounded by the Frobenius norm
+            double fo = 0.0, fw = 0.0, tw = 0.0;
+            for (int r = 0; r < 3; r++) {
+                for (int c = 0; c < 3; c++) {
+                    fo += a[r][c] * a[r][c];
+                    fw += double(s.w2o[r * 4 + c]) * double(s.w2o[r * 4 + c]);
+                }
+                tw += double(s.w2o[r * 4 + 3]) * double(s.w2o[r * 4 + 3]);
+            }
+            fo = std::sqrt(fo);
+            fw = std::sqrt(fw);
+            const double cond = fo * fw;   // >= true condition number (>= 1 for any invertible map, Frobenius >= spectral)
+            const double rad = std::fabs(double(s.radius)) * fo * 1.001 + 1e-30;
+            const double c2 = double(s.center[0]) * s.center[0] + double(s.center[1]) * s.center[1] + double(s.center[2]) * s.center[2];
+            // magnitudes of the object-space operands, mapped to world units with |o2w|
+            const double mag2 = cw[0] * cw[0] + cw[1] * cw[1] + cw[2] * cw[2] + rad * rad + fo * fo * (tw + c2 + double(s.radius) * s.radius);
+            ok = ok && std::isfinite(cond) && cond >= 1.0 && cond < 1e6 && std::isfinite(mag2) && std::isfinite(rad) && s.radius == s.radius;
+            b.center[0] = static_cast<float>(cw[0]);
+            b.center[1] = static_cast<float>(cw[1]);
+            b.center[2] = static_cast<float>(cw[2]);
+            b.radius = ok ? static_cast<float>(rad) : INFINITY;
+            b.radius2 = ok ? static_cast<float>(rad * rad * 1.000001) : INFINITY;
+            b.slack_scale = ok ? static_cast<float>(256.0 * 5.9604644775390625e-08 * cond * cond) : INFINITY;
+            b.magnitude2 = ok ? static_cast<float>(mag2 * 1.000001) : INFINITY;
+            b.pad = 0.0f;
+        }
+        if ((rc = upload(ctx, sb, &sc.sphere_bounds)) != RT_OK) return rc;
+    }
     if ((rc = upload(ctx, julias, &sc.julias)) != RT_OK) return rc;
     {
         // the shade blob: every table the shading code reads per lane, 16-byte aligned pieces

@@ -165,6 +165,75 @@ RT_DEV float julia_distance_tail(float m2, float d2) {
     return static_cast<float>(tail);
 }
 
+// The same value by a shorter route, for the march loop (one tail per march step).  E = sqrt(q) *
+// 0.25 * ln(m2) is evaluated in double with a relative error below 2^-51 (float-seeded Newton
+// square root and reciprocal, atanh series for the logarithm; error measured against 80-bit
+// arithmetic on 10^8 operands by the model in tools/fast_tail_model.c), the reference's own double
+// expression is within 2^-50 of the same real number, so both round to the same float unless E lies
+// within 2^-44*E of a rounding boundary.  That case, and every operand outside the plain range
+// (m2 < 4, infinities, NaNs, zero or denormal results), returns false and the caller evaluates the
+// reference's expression itself (julia_distance_tail).
+RT_DEV bool julia_distance_tail_fast(float m2, float d2, float& out) {
+    const float q = m2 / d2;
+    if (!(m2 >= 4.0f && m2 < __builtin_inff() && q >= 1e-30f && q < 1e30f)) return false;
+    const double x = static_cast<double>(q);
+    double g, h;
+    {
+        const double y = static_cast<double>(__builtin_amdgcn_rsqf(q));
+        g = x * y;
+        h = 0.5 * y;
+        double r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+        r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+        const double d = __builtin_fma(-g, g, x);
+        g = __builtin_fma(d, h, g);   // sqrt(q)
+    }
+    int e;
+    double m = __builtin_frexp(static_cast<double>(m2), &e);   // [0.5, 1)
+    if (m < 0.70710678118654752) {
+        m *= 2.0;
+        e -= 1;
+    }
+    const double num = m - 1.0, den = m + 1.0;
+    double ry = static_cast<double>(__builtin_amdgcn_rcpf(static_cast<float>(den)));
+    double er = __builtin_fma(-den, ry, 1.0);
+    ry = __builtin_fma(ry, er, ry);
+    er = __builtin_fma(-den, ry, 1.0);
+    ry = __builtin_fma(ry, er, ry);
+    const double s = num * ry;
+    const double s2 = s * s;
+    double p = 1.0 / 19.0;
+    p = __builtin_fma(p, s2, 1.0 / 17.0);
+    p = __builtin_fma(p, s2, 1.0 / 15.0);
+    p = __builtin_fma(p, s2, 1.0 / 13.0);
+    p = __builtin_fma(p, s2, 1.0 / 11.0);
+    p = __builtin_fma(p, s2, 1.0 / 9.0);
+    p = __builtin_fma(p, s2, 1.0 / 7.0);
+    p = __builtin_fma(p, s2, 1.0 / 5.0);
+    p = __builtin_fma(p, s2, 1.0 / 3.0);
+    p = p * s2;
+    const double lnm = 2.0 * __builtin_fma(s, p, s);
+    const double ln = __builtin_fma(static_cast<double>(e), 0.69314718055994530942, lnm);
+    const double big = g * 0.25 * ln;
+    const float f = static_cast<float>(big);
+    const unsigned bits = __float_as_uint(f);
+    const unsigned ex = bits & 0x7f800000u;
+    if ((bits & 0x007fffffu) == 0u || ex < (40u << 23) || ex == 0x7f800000u) return false;
+    const double half_ulp = static_cast<double>(__uint_as_float(ex - (24u << 23)));
+    const double resid = __builtin_fabs(big - static_cast<double>(f));
+    if (!(half_ulp - resid > __builtin_fabs(big) * 0x1p-44)) return false;
+    out = f;
+    return true;
+}
+RT_DEV float julia_distance_tail_auto(float m2, float d2) {
+    float r;
+    if (julia_distance_tail_fast(m2, d2, r)) return r;
+    return julia_distance_tail(m2, d2);
+}
+
 template <bool COUNT>
 RT_DEV float julia_distance(Quat z, Quat c, unsigned iterations, unsigned long long& n_iter) {
     float d2 = 1.0f;
@@ -238,8 +307,15 @@ RT_DEV int julia_advance(float dist, V3& p, V3 d, unsigned& i) {
 }
 template <bool COUNT>
 RT_DEV int julia_step(const DevJulia& j, V3& p, V3 d, unsigned& i, unsigned long long& n_iter) {
-    const float dist = julia_distance<COUNT>({p.x, p.y, p.z, j.cut_plane}, {j.c[0], j.c[1], j.c[2], j.c[3]}, kJuliaDistanceIterations, n_iter);
-    return julia_advance(dist, p, d, i);
+    Quat z = {p.x, p.y, p.z, j.cut_plane};
+    const Quat c = {j.c[0], j.c[1], j.c[2], j.c[3]};
+    float d2 = 1.0f;
+    float m2 = julia_norm2(z);
+    for (unsigned k = 0; k < kJuliaDistanceIterations; k++) {
+        if (COUNT) n_iter++;
+        if (julia_iterate(z, c, d2, m2)) break;
+    }
+    return julia_advance(julia_distance_tail_auto(m2, d2), p, d, i);
 }
 
 // Whole Julia::intersect in one go (used where no wave-level scheduling is worth it: the

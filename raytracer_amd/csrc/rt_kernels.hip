@@ -32,6 +32,7 @@ namespace rtd {
 #ifndef RT_TRI_GROUP
 #define RT_TRI_GROUP 4
 #endif
+static_assert(RT_TRI_GROUP == kTriChunk, "the triangle loop steps by one chunk of tri_chunks");
 #ifndef RT_SERVICE_THRESHOLD
 #define RT_SERVICE_THRESHOLD 16   // lanes waiting outside the march before it is interrupted
 #endif
@@ -232,6 +233,10 @@ RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, Counters& 
     const auto spheres = to_constant(sc.spheres);
     const auto obj_mat = to_constant(sc.object_material);
     const auto mats = to_constant(sc.materials);
+    const auto chunks = to_constant(sc.tri_chunks);
+    const auto sbounds = to_constant(sc.sphere_bounds);
+    const float oo = dot(L.qo, L.qo);
+    const V3 inv = {1.0f / L.qd.x, 1.0f / L.qd.y, 1.0f / L.qd.z};
     for (unsigned r = 0; r < sc.n_runs; r++) {
         const int kind = runs[r].kind;
         const unsigned first_object = runs[r].first_object, first_prim = runs[r].first_prim, count = runs[r].count;
@@ -242,6 +247,21 @@ RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, Counters& 
             // are finished one after the other in scene order against the running maximum.
             for (unsigned i = 0; i < count; i += RT_TRI_GROUP) {
                 if (!__any(act != 0u)) break;
+                {
+                    // skip the chunk when no open query of the wave can touch its bounds (slab test as in
+                    // query_bvh: NaNs of 0*inf dropped by fminf/fmaxf, far side widened)
+                    const auto cb = chunks + runs[r].first_chunk + i / RT_TRI_GROUP;
+                    const float x0 = (cb->lo[0] - L.qo.x) * inv.x, x1 = (cb->hi[0] - L.qo.x) * inv.x;
+                    const float y0 = (cb->lo[1] - L.qo.y) * inv.y, y1 = (cb->hi[1] - L.qo.y) * inv.y;
+                    const float z0 = (cb->lo[2] - L.qo.z) * inv.z, z1 = (cb->hi[2] - L.qo.z) * inv.z;
+                    const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                    const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                    const bool overlap = !(tnear > tfar * 1.0000004f) && !(tfar < 0.0f) && !(tnear > L.qmax);
+                    if (!__any(act != 0u && overlap)) {
+                        if (act != 0u) bump<STATS>(n, C_TRIANGLE_TESTS, count - i < RT_TRI_GROUP ? count - i : RT_TRI_GROUP);
+                        continue;
+                    }
+                }
                 TriGeom g[RT_TRI_GROUP];
                 TriStage1 s1[RT_TRI_GROUP];
 #pragma unroll
@@ -282,6 +302,21 @@ RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, Counters& 
         } else if (kind == RUN_SPHERES) {
             for (unsigned i = 0; i < count; i++) {
                 if (!__any(act != 0u)) break;
+                {
+                    // skip the sphere when every open query of the wave provably misses it: the ray passes
+                    // outside the bounding sphere, starts outside and points away, or the sphere lies
+                    // beyond the query's maximum (slack: DevSphereBound)
+                    const auto sb = sbounds + first_prim + i;
+                    const V3 vc = v3(sb->center[0], sb->center[1], sb->center[2]) - L.qo;
+                    const float cc = dot(vc, vc), bb = dot(vc, L.qd);
+                    const float slack = sb->slack_scale * (oo + sb->magnitude2);
+                    const float lim = sb->radius2 + slack;
+                    const bool miss = (cc - bb * bb > lim) || (cc > lim && (bb < 0.0f || bb - sb->radius > L.qmax * 1.001f + slack));
+                    if (!__any(act != 0u && !miss)) {
+                        if (act != 0u) bump<STATS>(n, C_SPHERE_TESTS);
+                        continue;
+                    }
+                }
                 if (act != 0u) {
                     bump<STATS>(n, C_SPHERE_TESTS);
                     HitRec h;

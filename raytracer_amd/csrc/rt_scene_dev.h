@@ -19,7 +19,8 @@ struct DevRun {
     uint32_t count;
     uint32_t bvh_root;       // RUN_TRIANGLE_BVH: first node of this run's BVH
     uint32_t material;       // RUN_TRIANGLE_BVH: the run's single material
-    uint32_t pad0, pad1;
+    uint32_t first_chunk;    // RUN_TRIANGLES: first entry of this run in tri_chunks
+    uint32_t pad1;
 };
 
 // What the Möller–Trumbore test needs (edges precomputed with the reference's own subtraction,
@@ -39,6 +40,16 @@ struct DevSphere {
     float center[3];
     float radius;
     float w2o[12], o2w[12], o2wn[12];
+};
+// World-space bounding sphere of a DevSphere (an ellipsoid after its transform) with the slack that
+// makes "outside" a proof that Sphere::intersect as written returns no hit (rt_api.hip).  32 bytes.
+struct DevSphereBound {
+    float center[3];
+    float radius;            // grown by 1e-3
+    float radius2;           // radius^2
+    float slack_scale;       // slack = slack_scale * (|origin|^2 + magnitude2): bound on the float error of src/objects.cpp:12-31
+    float magnitude2;        // |center|^2 + radius^2 + |object-space centre|^2 ...
+    float pad;
 };
 // 192 bytes
 struct DevJulia {
@@ -71,6 +82,16 @@ struct DevLight {
     int type;
     float power[4];
 };
+// Bounds of kTriChunk consecutive triangles of a RUN_TRIANGLES run (conservative for
+// Triangle::intersect as written, like the BVH leaf boxes).  A chunk that no ray of the wave can
+// touch is skipped as a whole; the chunks are still visited in scene order.  32 bytes.
+constexpr uint32_t kTriChunk = 4;
+struct DevTriChunk {
+    float lo[3];
+    float pad0;
+    float hi[3];
+    float pad1;
+};
 // 32-byte BVH node: leaf when count > 0
 struct DevBvhNode {
     float lo[3];
@@ -98,7 +119,9 @@ struct DevScene {
     const DevRun* runs;
     const DevTriTest* tri_test;
     const DevTriShade* tri_shade;
+    const DevTriChunk* tri_chunks;
     const DevSphere* spheres;
+    const DevSphereBound* sphere_bounds;
     const DevJulia* julias;
     const uint32_t* object_material;   // [n_objects]
     const int32_t* object_photon_slot; // [n_objects] slot in the photon atlas or -1

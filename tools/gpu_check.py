@@ -26,8 +26,11 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--save", default="")
+    ap.add_argument("--bvh-min", type=int, default=None)
     args = ap.parse_args()
     ctx = capi.Context(0)
+    if args.bvh_min is not None:
+        ctx.set_option(capi.RT_OPT_BVH_MIN_TRIANGLES, args.bvh_min)
     for path in args.scenes:
         sc = capi.Scene(path, args.t)
         if args.width or args.height or args.ss:
