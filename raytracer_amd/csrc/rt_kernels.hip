@@ -531,11 +531,39 @@ RT_DEV void resolve_lane(const DevScene& sc, const ShadeTables& T, const DevJob&
             const V3 refl = normalized(L.n_normal * ndotl * 2.0f - L.qd);
             const float rv = dot(refl, L.n_dir * -1.0f);
             const float sbase = rv < 0.0f ? 0.0f : rv;
-            const float spow = static_cast<float>(pow(static_cast<double>(sbase), static_cast<double>(m.exponent)));   // Y8
+            float diffuse[3];
+            for (int c = 0; c < 3; c++) diffuse[c] = light.power[c] * L.matcol[c] * lambert * m.kd;
+            // pow(double, double) is ~250 instructions; most lit points are far from the highlight, where
+            // its value cannot change the sum below.  With ub >= pow(sbase, exponent) (hardware log2/exp2,
+            // 1 % and 2^-6 in the exponent to spare) the term is dropped when it is below a quarter ulp of
+            // the diffuse term it is added to in every channel (then fl(diffuse + specular) == diffuse),
+            // or when the float result is exactly zero; everything else takes the reference's expression.
+            float spow = 0.0f;
+            bool exact = true;
+            if (m.exponent > 0.0f && m.exponent < 1e6f) {
+                if (sbase == 0.0f) {
+                    exact = false;                                   // pow(+0, y > 0) = +0
+                } else if (sbase < 1.0f) {
+                    const float lg = m.exponent * __builtin_amdgcn_logf(sbase) + 0.015625f;   // log2, rounded up
+                    if (lg < -160.0f) {
+                        exact = false;                               // < 2^-150: rounds to +0 as a float
+                    } else {
+                        const float ub = __builtin_amdgcn_exp2f(lg) * 1.01f;
+                        bool negligible = true;
+                        for (int c = 0; c < 3; c++) {
+                            const float s_ub = fabsf(light.power[c] * m.ks) * ub;
+                            negligible = negligible && (light.power[c] * m.ks == 0.0f || s_ub < fabsf(diffuse[c]) * 0x1p-26f);
+                        }
+                        // the products power*spow*ks of the dropped term must not matter either way: they
+                        // are below 2^-26 of a finite diffuse term, so they are finite and the sum is diffuse
+                        if (negligible) exact = false;
+                    }
+                }
+            }
+            if (exact) spow = static_cast<float>(pow(static_cast<double>(sbase), static_cast<double>(m.exponent)));   // Y8
             for (int c = 0; c < 3; c++) {
-                const float diffuse = light.power[c] * L.matcol[c] * lambert * m.kd;
                 const float specular = light.power[c] * spow * m.ks;
-                L.acc[c] = L.acc[c] + (diffuse + specular);
+                L.acc[c] = L.acc[c] + (diffuse[c] + specular);
             }
         }
         L.li++;
