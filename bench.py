@@ -40,7 +40,19 @@ FLOPS = {"triangle_tests": 29, "sphere_tests": 59, "shaded_hits": 64, "phong_lig
          "texture_lookups": 40, "primary_rays": 60, "secondary_rays": 37, "julia_de_iterations": 41,
          "julia_steps": 11, "julia_normals": 36, "julia_queries": 30, "photon_segments": 37,
          "bvh_node_visits": 21}   # ours, not the reference's: slab test of one node (6 sub, 6 mul, 6 min/max, 3 compares)
-PEAK_FP32_TFLOPS = 157.3   # MI355X FP32 vector peak (MI355X_MICROARCH.md)
+PEAK_FP32_TFLOPS = 157.3   # MI355X FP32 vector peak (MI355X_MICROARCH.md); assumes packed FMA
+ISSUE_CEILING_TFLOPS = 39.3   # 256 CUs x 64 lanes x 2.4 GHz: one non-fused mul or add per lane and clock
+
+
+def measured_traffic(workload):
+    """HBM bytes per trace_kernel launch from the committed PMC passes (profiles/traffic.json, made by
+    tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this bench; FETCH_SIZE doubled
+    as MI355X_MICROARCH.md prescribes for gfx950).  None when no pass exists for the workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def algorithmic_flops(stats_dict):
@@ -116,6 +128,13 @@ def main():
     has_photons = scene.desc.photon_steps > 0
 
     # ---- counters (untimed): rays and algorithmic flops of one step on this rank ------------------
+    # Algorithmic work = the counts of the reference's formulation (nearest hit by a scan over all
+    # objects, then shade once), which the counters of a BVH-less launch reproduce exactly
+    # (pinned to the oracle's by tests/test_gpu_parity.py).  Culling and the BVH skip part of that work;
+    # they do not change the numerator.
+    if args.bvh_min is None:
+        ctx.set_option(capi.RT_OPT_BVH_MIN_TRIANGLES, 1 << 40)
+        ctx.upload(scene)
     ctx.set_option(capi.RT_OPT_COLLECT_STATS, 1)
     pst = ctx.photon_generate()
     ctx.render_device(frame.data_ptr(), stream)
@@ -125,6 +144,9 @@ def main():
     rays_per_step = stats["primary_rays"] + stats["secondary_rays"] + stats["shadow_rays"] + stats["photon_segments"]
     flops_per_step = algorithmic_flops(stats)
     ctx.set_option(capi.RT_OPT_COLLECT_STATS, 0)
+    if args.bvh_min is None:
+        ctx.set_option(capi.RT_OPT_BVH_MIN_TRIANGLES, capi.RT_DEFAULT_BVH_MIN_TRIANGLES)
+        ctx.upload(scene)
 
     def step(events=None):
         if has_photons:
@@ -169,7 +191,8 @@ def main():
                        "frames_per_step": world, "sec_per_frame": elapsed / args.steps,
                        "parallelism": "frames sharded over ranks, RGBA8 frames gathered to rank 0 over RCCL" if world > 1 else "1 GPU"},
             "roofline": {"bound": "valu", "kernel": "trace_kernel", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": measured_traffic(args.workload),
+                         "frac_of_unfused_issue_ceiling": achieved / ISSUE_CEILING_TFLOPS,
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops_per_step,
                          "note": "FP32 VALU bound (no HBM or MFMA roofline applies: scene is KBs, nothing is a contraction); see DESIGN.md"},
         }
