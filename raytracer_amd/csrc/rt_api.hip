@@ -6,6 +6,7 @@
 // rt_kernels.hip.  No CPU fallback exists: without a HIP device every entry point fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -19,6 +20,8 @@
 namespace rtd {
 template <bool HAS_JULIA, bool STATS>
 __global__ void trace_kernel(const DevScene sc, const DevJob job);
+template <bool STATS>
+__global__ void trace_julia_kernel(const DevScene sc, const DevJob job);
 template <bool HAS_JULIA, bool STATS>
 __global__ void photon_kernel(const DevScene sc, const DevPhotonJob job);
 __global__ void sum_samples_kernel(const float4* samples, float4* out, unsigned long long n_pixels, unsigned samples_per_pixel, float inv_samples);
@@ -29,6 +32,8 @@ __global__ void quantize_kernel(const float4* rgba, uchar4* out, float gain, uns
 hipError_t build_triangle_bvh(const DevTriTest* tris, uint32_t first, uint32_t n, DevBvhNode* nodes);
 constexpr int kFrameFieldsHost = 11;
 constexpr size_t kMaxLdsBlobBytes = 36 * 1024;   // keeps 4 blocks per CU within the 160 KB LDS
+constexpr size_t kMaxLdsBlobBytesJulia = 64 * 1024 - kJuliaStaticLdsBytes;   // trace_julia_kernel: blob + its queues stay under 64 KB
+constexpr int kJuliaBlockThreads = kJuliaWaves * 64, kJuliaTracerLanesHost = (kJuliaWaves - kJuliaMarcherWaves) * 64;
 }  // namespace rtd
 
 using namespace rtd;
@@ -161,11 +166,24 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     const bool stats = ctx->collect_stats;
     int blocks = 0;
     int rc;
-    const size_t lds = ctx->dev.shade_blob_in_lds ? ctx->dev.shade_blob_bytes : 0;
-    if (julia) rc = stats ? persistent_grid(ctx, trace_kernel<true, true>, job.n_samples, &blocks, lds) : persistent_grid(ctx, trace_kernel<true, false>, job.n_samples, &blocks, lds);
-    else rc = stats ? persistent_grid(ctx, trace_kernel<false, true>, job.n_samples, &blocks, lds) : persistent_grid(ctx, trace_kernel<false, false>, job.n_samples, &blocks, lds);
-    if (rc != RT_OK) return rc;
-    const uint64_t lanes = static_cast<uint64_t>(blocks) * 256;
+    DevScene dev = ctx->dev;
+    if (julia && dev.shade_blob_bytes > kMaxLdsBlobBytesJulia) dev.shade_blob_in_lds = 0;
+    const size_t lds = dev.shade_blob_in_lds ? dev.shade_blob_bytes : 0;
+    uint64_t lanes;
+    if (julia) {
+        // one workgroup of tracer and marcher waves per CU (trace_julia_kernel)
+        int per_cu = 0;
+        if (stats) RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_julia_kernel<true>, kJuliaBlockThreads, lds));
+        else RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_julia_kernel<false>, kJuliaBlockThreads, lds));
+        if (per_cu < 1) return fail(ctx, RT_ERR_HIP, "trace_julia_kernel does not fit a compute unit");
+        const uint64_t needed = (job.n_samples + kJuliaTracerLanesHost - 1) / kJuliaTracerLanesHost;
+        blocks = static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(ctx->n_cus), needed ? needed : 1));
+        lanes = static_cast<uint64_t>(blocks) * kJuliaTracerLanesHost;
+    } else {
+        rc = stats ? persistent_grid(ctx, trace_kernel<false, true>, job.n_samples, &blocks, lds) : persistent_grid(ctx, trace_kernel<false, false>, job.n_samples, &blocks, lds);
+        if (rc != RT_OK) return rc;
+        lanes = static_cast<uint64_t>(blocks) * 256;
+    }
     rc = grow(ctx, ctx->stack, lanes * (ctx->dev.max_bounces + 1) * kFrameFieldsHost * sizeof(float));
     if (rc != RT_OK) return rc;
     if (job.samples_per_pixel > 1) {
@@ -177,15 +195,15 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     job.stack = static_cast<float*>(ctx->stack.ptr);
     job.queue_head = ctx->d_queue;
     job.counters = ctx->d_counters;
-    RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), stream));
+    RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 2 * sizeof(unsigned long long), stream));   // [0] queue head, [1] watchdog flag
     RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long), stream));
     RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
     if (julia) {
-        if (stats) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
-        else hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
+        if (stats) hipLaunchKernelGGL((trace_julia_kernel<true>), dim3(blocks), dim3(kJuliaBlockThreads), lds, stream, dev, job);
+        else hipLaunchKernelGGL((trace_julia_kernel<false>), dim3(blocks), dim3(kJuliaBlockThreads), lds, stream, dev, job);
     } else {
-        if (stats) hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
-        else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
+        if (stats) hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(256), lds, stream, dev, job);
+        else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(256), lds, stream, dev, job);
     }
     RT_HIP_TRY(ctx, hipGetLastError());
     if (job.samples_per_pixel > 1) {
@@ -250,6 +268,9 @@ int read_stats(rt_ctx* ctx, rt_stats* out) {
     std::memset(out, 0, sizeof *out);
     unsigned long long c[C_COUNT];
     RT_HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    unsigned long long q[2] = {0, 0};
+    RT_HIP_TRY(ctx, hipMemcpy(q, ctx->d_queue, sizeof q, hipMemcpyDeviceToHost));
+    if (q[1] != 0) return fail(ctx, RT_ERR_HIP, "trace_julia_kernel: a wave waited too long on the job queues and the launch was abandoned");
     out->primary_rays = c[C_PRIMARY];
     out->secondary_rays = c[C_SECONDARY];
     out->shadow_rays = c[C_SHADOW];

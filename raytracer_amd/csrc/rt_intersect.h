@@ -228,6 +228,12 @@ RT_DEV float julia_distance_tail(float m2, float d2) {
 // (m2 < 4, infinities, NaNs, zero or denormal results), returns false and the caller evaluates the
 // reference's expression itself (julia_distance_tail).
 RT_DEV bool julia_distance_tail_fast(float m2, float d2, float& out) {
+    if (d2 == __builtin_inff() && m2 > 0.0f && m2 < __builtin_inff()) {
+        // interior point: sqrt(m2/inf) = 0 times a finite logarithm; the sign of the zero is never looked
+        // at (julia_advance only compares it with the thresholds)
+        out = 0.0f;
+        return true;
+    }
     const float q = m2 / d2;
     if (!(m2 >= 4.0f && m2 < __builtin_inff() && q >= 1e-30f && q < 1e30f)) return false;
     const double x = static_cast<double>(q);

@@ -814,6 +814,433 @@ __global__ __launch_bounds__(256, HAS_JULIA ? RT_TRACE_WAVES_JULIA : RT_TRACE_WA
     flush_counters<STATS>(n, job.counters);
 }
 
+// ---- the render kernel for scenes with Julia sets -------------------------------------------------------
+// Marching a Julia set costs 10^2..10^6 times what the rest of a ray's life costs, and a march step's
+// own cost (iterations of the distance estimator) varies by 10x from lane to lane.  So the work is
+// split by ROLE inside a workgroup of kJuliaWaves waves:
+//   * tracer waves own rays (one per lane, exactly as trace_kernel does) and run the query / resolve
+//     phases; a ray that enters a Julia set's bounding sphere becomes a JOB in LDS (one record per
+//     owner lane) whose owner id is pushed on a ring in LDS, and the lane waits;
+//   * marcher waves (one per SIMD) pop jobs into ALL 64 lanes and march them; a lane that finishes a
+//     job takes the next one at once, so the march loop always runs full.  The estimator's iterations
+//     run in blocks of four for the wave; lanes whose estimate is complete take their march step
+//     (tail + advance) together as soon as a kJuliaStepDivisor-th of the lanes wait for one;
+//   * converged jobs go to a second ring and are finished (normal estimate, world-space hit) 64 at a
+//     time by whichever marcher finds a full batch, or a partial one when it has nothing else to do.
+// Queues, job records and results never leave LDS; HBM only sees the sample buffer and frame stacks.
+constexpr int kJuliaTracerLanes = (kJuliaWaves - kJuliaMarcherWaves) * 64;   // owners per workgroup
+constexpr unsigned kJuliaQueueCap = kJuliaTracerLanes <= 512 ? 512u : 1024u;    // an owner has at most one job in flight
+static_assert(sizeof(float) * 11 * kJuliaTracerLanes + 16 * kJuliaQueueCap + 64 <= kJuliaStaticLdsBytes, "kJuliaStaticLdsBytes");
+static_assert(kJuliaQueueCap >= kJuliaTracerLanes && (kJuliaQueueCap & (kJuliaQueueCap - 1)) == 0, "ring size");
+#ifndef RT_JULIA_STEP_DIVISOR
+#define RT_JULIA_STEP_DIVISOR 3
+#endif
+#ifndef RT_JULIA_TRACER_MIN_READY
+#define RT_JULIA_TRACER_MIN_READY 24        // a tracer wave waits for this many serviceable lanes while the marchers have work
+#endif
+constexpr unsigned kSpinLimit = 1u << 24;   // polling rounds before a wave declares the launch stuck
+
+enum JobField : int { JF_PX = 0, JF_PY, JF_PZ, JF_DX, JF_DY, JF_DZ, JF_OX, JF_OY, JF_OZ, JF_JULIA, JF_STATUS, JF_COUNT };
+enum JobStatus : unsigned { JOB_PENDING = 0u, JOB_MISS = 1u, JOB_HIT = 2u };
+
+struct JuliaRing {
+    unsigned ids[kJuliaQueueCap];           // owner id of entry i at [i & (cap-1)]
+    unsigned ready[kJuliaQueueCap];         // == i+1 once entry i has been written
+};
+// running counts (never wrapped) of the two rings; entries head..tail-1 are reserved.  One 16-byte
+// record so that a marcher reads all four with a single LDS load.
+enum CtlWord : int { CTL_MARCH_HEAD = 0, CTL_MARCH_TAIL = 1, CTL_NORMAL_HEAD = 2, CTL_NORMAL_TAIL = 3 };
+struct JuliaShared {
+    __attribute__((aligned(16))) unsigned ctl[4];
+    unsigned tracers_done, abort, hungry, pad;
+    float job[JF_COUNT][kJuliaTracerLanes]; // SoA job records; results overwrite P (world point), D (world normal), OX (distance)
+    JuliaRing march, normal;
+};
+
+RT_DEV unsigned lds_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+RT_DEV void lds_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+RT_DEV float lds_loadf(const float* p) { return __uint_as_float(lds_load(reinterpret_cast<const unsigned*>(p))); }
+RT_DEV void lds_storef(float* p, float v) { lds_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v)); }
+RT_DEV void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+RT_DEV void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+
+// Lanes with `want` set append their owner id to the ring (one LDS atomic per wave).
+RT_DEV void ring_push(JuliaRing& q, unsigned* tail_word, bool want, unsigned id) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = __hip_atomic_fetch_add(tail_word, static_cast<unsigned>(__popcll(mask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    base = __shfl(base, leader);
+    if (want) {
+        const unsigned i = base + __popcll(mask & ((1ull << lane) - 1ull));
+        lds_store(&q.ids[i & (kJuliaQueueCap - 1)], id);
+        lds_release();
+        lds_store(&q.ready[i & (kJuliaQueueCap - 1)], i + 1u);
+    }
+}
+// Reserves up to `want_n` entries for this wave; returns how many and the index of the first.
+RT_DEV unsigned ring_pop(unsigned* head_word, const unsigned* tail_word, unsigned want_n, unsigned& first) {
+    unsigned got = 0, h = 0;
+    if ((threadIdx.x & 63) == 0 && want_n > 0) {
+        for (int attempt = 0; attempt < 64; attempt++) {
+            h = lds_load(head_word);
+            const unsigned t = lds_load(tail_word);
+            const unsigned avail = t - h;
+            if (avail == 0u || avail > kJuliaQueueCap) break;
+            const unsigned take = avail < want_n ? avail : want_n;
+            unsigned expect = h;
+            if (__hip_atomic_compare_exchange_strong(head_word, &expect, h + take, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                got = take;
+                break;
+            }
+        }
+    }
+    got = __shfl(got, 0);
+    first = __shfl(h, 0);
+    return got;
+}
+// Owner id of reserved entry i (waits for the producer's write; bounded).
+RT_DEV unsigned ring_entry(JuliaRing& q, unsigned i, unsigned* abort_flag) {
+    unsigned spins = 0;
+    while (lds_load(&q.ready[i & (kJuliaQueueCap - 1)]) != i + 1u) {
+        if (++spins > kSpinLimit) {
+            lds_store(abort_flag, 1u);
+            return 0u;
+        }
+    }
+    lds_acquire();
+    return lds_load(&q.ids[i & (kJuliaQueueCap - 1)]);
+}
+
+template <bool STATS>
+RT_DEV void julia_marcher(const DevScene& sc, JuliaShared& sh, Counters& n) {
+    const int lane = threadIdx.x & 63;
+    bool has = false, busy = false;
+    unsigned owner = 0, jidx = 0, jstep = 0, it = 0;
+    V3 p = {0, 0, 0}, d = {0, 0, 0};
+    JuliaPk s = julia_pk_begin({0, 0, 0, 0});
+    PkF2 cp = {0, 0}, cq = {0, 0};
+    float cut = 0.0f;
+    unsigned idle_rounds = 0;
+    long long t_mark = STATS ? clock64() : 0;
+    auto charge = [&](int slot) {
+        if (STATS) {
+            const long long now = clock64();
+            if (lane == 0) n.v[slot] += static_cast<unsigned long long>(now - t_mark);
+            t_mark = now;
+        }
+    };
+    unsigned round = 0;
+    for (;;) {
+        // The rings are looked at when enough lanes are idle to make the LDS round trips worth it (or
+        // every eighth round, so that no job waits long).
+        const int n_has0 = __popcll(__ballot(has));
+        round++;
+        if (n_has0 <= 56 || (round & 7u) == 0u) {
+            typedef unsigned U4 __attribute__((ext_vector_type(4)));
+            typedef unsigned U2 __attribute__((ext_vector_type(2)));
+            const U4 ctl = *reinterpret_cast<volatile U4*>(sh.ctl);
+            const U2 flags = *reinterpret_cast<volatile U2*>(&sh.tracers_done);   // tracers_done, abort
+            if (flags.y != 0u) break;
+            const unsigned n_conv = ctl.w - ctl.z, n_jobs = ctl.y - ctl.x;
+            // ---- finish converged jobs: a full batch at once, a partial one when there is little else to do
+            if (n_conv >= 64u || (n_conv > 0u && n_has0 < 32 && n_jobs == 0u)) {
+                unsigned first = 0;
+                const unsigned got = ring_pop(&sh.ctl[CTL_NORMAL_HEAD], &sh.ctl[CTL_NORMAL_TAIL], 64u, first);
+                if (static_cast<unsigned>(lane) < got) {
+                    const unsigned o = ring_entry(sh.normal, first + lane, &sh.abort);
+                    const DevJulia& j = sc.julias[__float_as_uint(lds_loadf(&sh.job[JF_JULIA][o]))];
+                    const V3 jp = v3(lds_loadf(&sh.job[JF_PX][o]), lds_loadf(&sh.job[JF_PY][o]), lds_loadf(&sh.job[JF_PZ][o]));
+                    const V3 jd = v3(lds_loadf(&sh.job[JF_DX][o]), lds_loadf(&sh.job[JF_DY][o]), lds_loadf(&sh.job[JF_DZ][o]));
+                    const V3 ow = v3(lds_loadf(&sh.job[JF_OX][o]), lds_loadf(&sh.job[JF_OY][o]), lds_loadf(&sh.job[JF_OZ][o]));
+                    bump<STATS>(n, C_JULIA_NORMALS);
+                    unsigned long long iters = 0;
+                    HitRec h;
+                    // the distance limits of src/objects.cpp:236 are applied by the owner (it knows the query)
+                    const bool hit = julia_finish<STATS>(j, ow, jp, jd, kInfinite, h, iters);
+                    bump<STATS>(n, C_JULIA_DE_ITERATIONS, iters);
+                    if (hit) {
+                        lds_storef(&sh.job[JF_PX][o], h.point.x);
+                        lds_storef(&sh.job[JF_PY][o], h.point.y);
+                        lds_storef(&sh.job[JF_PZ][o], h.point.z);
+                        lds_storef(&sh.job[JF_DX][o], h.normal.x);
+                        lds_storef(&sh.job[JF_DY][o], h.normal.y);
+                        lds_storef(&sh.job[JF_DZ][o], h.normal.z);
+                        lds_storef(&sh.job[JF_OX][o], h.dist);
+                    }
+                    lds_release();
+                    lds_storef(&sh.job[JF_STATUS][o], __uint_as_float(hit ? JOB_HIT : JOB_MISS));
+                }
+                if (STATS && lane == 0) n.v[D_NORMAL_PHASES]++;
+                if (STATS && static_cast<unsigned>(lane) < got) n.v[D_NORMAL_LANES]++;
+                charge(D_NORMAL_CYCLES);
+                continue;
+            }
+            // ---- refill idle lanes from the march ring
+            const unsigned long long need = __ballot(!has);
+            if (need != 0ull && n_jobs != 0u) {
+                unsigned first = 0;
+                const unsigned got = ring_pop(&sh.ctl[CTL_MARCH_HEAD], &sh.ctl[CTL_MARCH_TAIL], static_cast<unsigned>(__popcll(need)), first);
+                const unsigned rank = __popcll(need & ((1ull << lane) - 1ull));
+                if (!has && rank < got) {
+                    owner = ring_entry(sh.march, first + rank, &sh.abort);
+                    jidx = __float_as_uint(lds_loadf(&sh.job[JF_JULIA][owner]));
+                    p = v3(lds_loadf(&sh.job[JF_PX][owner]), lds_loadf(&sh.job[JF_PY][owner]), lds_loadf(&sh.job[JF_PZ][owner]));
+                    d = v3(lds_loadf(&sh.job[JF_DX][owner]), lds_loadf(&sh.job[JF_DY][owner]), lds_loadf(&sh.job[JF_DZ][owner]));
+                    const DevJulia& j = sc.julias[jidx];
+                    cp = {j.c[0], j.c[1]};
+                    cq = {j.c[2], j.c[3]};
+                    cut = j.cut_plane;
+                    jstep = 0;
+                    s = julia_pk_begin({p.x, p.y, p.z, cut});
+                    it = 0;
+                    has = true;
+                    busy = true;
+                }
+            }
+            // tell the tracers whether this wave runs short of jobs (they then stop waiting for full phases)
+            const int n_now = __popcll(__ballot(has));
+            if (lane == 0) {
+                const unsigned hungry = n_now < 40 ? 1u : 0u;
+                if (lds_load(&sh.hungry) != hungry) lds_store(&sh.hungry, hungry);
+            }
+            if (n_now == 0) {
+                if (flags.x >= static_cast<unsigned>(kJuliaWaves - kJuliaMarcherWaves) && n_jobs == 0u && n_conv == 0u) break;
+                __builtin_amdgcn_s_sleep(8);
+                if (++idle_rounds > kSpinLimit) lds_store(&sh.abort, 1u);
+                charge(D_M_IDLE_CYCLES);
+                continue;
+            }
+        }
+        const int n_has = __popcll(__ballot(has));
+        idle_rounds = 0;
+        charge(D_M_REFILL_CYCLES);
+        if (STATS && lane == 0) n.v[D_MARCH_PHASES]++;
+        if (STATS && has) n.v[D_MARCH_LANES]++;
+        // ---- estimator iterations, four at a time, until enough lanes wait for their march step
+        for (;;) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (has && busy) {
+                    bump<STATS>(n, C_JULIA_DE_ITERATIONS);
+                    it++;
+                    if (julia_pk_iterate(s, cp, cq) || it >= kJuliaDistanceIterations) busy = false;
+                }
+            }
+            if (STATS && lane == 0) n.v[D_DE_WAVE_ITERS] += 256ull;
+            const int n_busy = __popcll(__ballot(has && busy));
+            if (n_busy == 0 || (n_has - n_busy) * RT_JULIA_STEP_DIVISOR >= n_has) break;
+        }
+        charge(D_MARCH_CYCLES);
+        if (STATS && lane == 0) n.v[D_M_TAIL_BLOCKS]++;
+        if (STATS && has && !busy) n.v[D_M_TAIL_LANES]++;
+        // ---- march steps of the lanes whose estimate is complete (src/objects.cpp:206-221)
+        bool converged = false;
+        if (has && !busy) {
+            bump<STATS>(n, C_JULIA_STEPS);
+            const int r = julia_advance(julia_distance_tail_auto(s.m2, s.d2), p, d, jstep);
+            if (r == 0) {
+                s = julia_pk_begin({p.x, p.y, p.z, cut});
+                it = 0;
+                busy = true;
+            } else {
+                has = false;
+                if (r == 1) {
+                    converged = true;
+                    lds_storef(&sh.job[JF_PX][owner], p.x);
+                    lds_storef(&sh.job[JF_PY][owner], p.y);
+                    lds_storef(&sh.job[JF_PZ][owner], p.z);
+                } else {
+                    lds_storef(&sh.job[JF_STATUS][owner], __uint_as_float(JOB_MISS));
+                }
+            }
+        }
+        ring_push(sh.normal, &sh.ctl[CTL_NORMAL_TAIL], converged, owner);
+        charge(D_M_TAIL_CYCLES);
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia_kernel(const DevScene sc_global, const DevJob job) {
+    extern __shared__ __align__(16) unsigned char lds_blob[];
+    __shared__ JuliaShared sh;
+    const DevScene& sc = sc_global;
+    const unsigned char* table_base = sc.shade_blob;
+    for (unsigned i = threadIdx.x; i < kJuliaQueueCap; i += blockDim.x) {
+        sh.march.ready[i] = 0u;
+        sh.normal.ready[i] = 0u;
+    }
+    if (threadIdx.x == 0) {
+        sh.ctl[0] = sh.ctl[1] = sh.ctl[2] = sh.ctl[3] = 0u;
+        sh.tracers_done = 0u;
+        sh.abort = 0u;
+        sh.hungry = 1u;
+        sh.pad = 0u;
+    }
+    if (sc.shade_blob_in_lds) {
+        for (unsigned i = threadIdx.x * 16u; i < sc.shade_blob_bytes; i += blockDim.x * 16u) {
+            *reinterpret_cast<uint4*>(lds_blob + i) = *reinterpret_cast<const uint4*>(sc.shade_blob + i);
+        }
+        table_base = lds_blob;
+    }
+    __syncthreads();
+    const ShadeTables T = tables_of(sc, table_base);
+    Counters n;
+    if (STATS) for (int i = 0; i < C_COUNT; i++) n.v[i] = 0;
+    const int wave = threadIdx.x >> 6;
+    if (wave < kJuliaMarcherWaves) {
+        julia_marcher<STATS>(sc, sh, n);
+        if (lds_load(&sh.abort) != 0u && (threadIdx.x & 63) == 0) atomicExch(job.queue_head + 1, 1ull);
+        flush_counters<STATS>(n, job.counters);
+        return;
+    }
+
+    // ---- tracer waves ---------------------------------------------------------------------------------
+    const unsigned owner = threadIdx.x - kJuliaMarcherWaves * 64;
+    const unsigned long long grid_lanes = static_cast<unsigned long long>(gridDim.x) * kJuliaTracerLanes;
+    const unsigned long long gid = static_cast<unsigned long long>(blockIdx.x) * kJuliaTracerLanes + owner;
+    const FrameRef stack = {job.stack + gid, grid_lanes};
+    Lane L;
+    L.state = S_RESOLVE;       // "resolve" of a lane without a sample = fetch one
+    L.qkind = -1;
+    L.sp = 0;
+    L.jidx = 0;
+    L.jstep = 0;
+    bool fresh = true;
+    unsigned wait_rounds = 0;
+    // S_MARCH here means: a job of this lane is with the marchers
+    long long t_mark = STATS ? clock64() : 0;
+    auto charge = [&](int slot) {
+        if (STATS) {
+            const long long now = clock64();
+            if ((threadIdx.x & 63) == 0) n.v[slot] += static_cast<unsigned long long>(now - t_mark);
+            t_mark = now;
+        }
+    };
+    for (;;) {
+        if (lds_load(&sh.abort) != 0u) break;
+        // ---- collect finished jobs (Julia::intersect's last checks and the acceptance rule)
+        bool push = false;
+        if (L.state == S_MARCH) {
+            const unsigned st = __float_as_uint(lds_loadf(&sh.job[JF_STATUS][owner]));
+            if (st != JOB_PENDING) {
+                lds_acquire();
+                const DevJulia& j = sc.julias[L.jidx];
+                if (st == JOB_HIT) {
+                    HitRec h;
+                    h.dist = lds_loadf(&sh.job[JF_OX][owner]);
+                    h.point = v3(lds_loadf(&sh.job[JF_PX][owner]), lds_loadf(&sh.job[JF_PY][owner]), lds_loadf(&sh.job[JF_PZ][owner]));
+                    h.normal = v3(lds_loadf(&sh.job[JF_DX][owner]), lds_loadf(&sh.job[JF_DY][owner]), lds_loadf(&sh.job[JF_DZ][owner]));
+                    h.uv = {0.0f, 0.0f};
+                    h.ph = {0.0f, 0.0f};
+                    // Julia::intersect ignores max_distance until this final check (src/objects.cpp:236)
+                    const float limit = L.qkind == Q_SHADOW ? L.qmax : kInfinite;
+                    if (!(h.dist > limit)) accept_julia_hit(L, h, j, T.materials[j.material]);
+                }
+                L.state = S_RESOLVE;
+                if (L.qactive) {
+                    // next Julia set of the scene, if any
+                    for (unsigned k = L.jidx + 1; k < sc.n_julias; k++) {
+                        bump<STATS>(n, C_JULIA_QUERIES);
+                        if (julia_enter(sc.julias[k], L.qo, L.qd, L.jp, L.jd)) {
+                            L.jidx = k;
+                            L.state = S_MARCH;
+                            push = true;
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+        const int n_query = __popcll(__ballot(L.state == S_QUERY));
+        const int n_resolve = __popcll(__ballot(L.state == S_RESOLVE));
+        const int n_wait = __popcll(__ballot(L.state == S_MARCH));
+        int phase = 0;
+        if (n_query + n_resolve == 0) {
+            if (n_wait == 0) break;
+        } else if (n_wait == 0 || n_query + n_resolve >= RT_JULIA_TRACER_MIN_READY || lds_load(&sh.hungry) != 0u || wait_rounds > 64u) {
+            phase = n_query >= n_resolve ? S_QUERY : S_RESOLVE;
+        }
+        if (phase == S_QUERY) {
+            const bool mine = L.state == S_QUERY;
+            if (STATS) {
+                if ((threadIdx.x & 63) == 0) n.v[D_QUERY_PHASES]++;
+                if (mine) n.v[D_QUERY_LANES]++;
+            }
+            query_objects<STATS>(sc, L, mine, n);
+            if (mine) {
+                L.state = S_RESOLVE;
+                if (L.qactive) {
+                    for (unsigned k = 0; k < sc.n_julias; k++) {
+                        bump<STATS>(n, C_JULIA_QUERIES);
+                        if (julia_enter(sc.julias[k], L.qo, L.qd, L.jp, L.jd)) {
+                            L.jidx = k;
+                            L.state = S_MARCH;
+                            push = true;
+                            break;
+                        }
+                    }
+                }
+            }
+        } else if (phase == S_RESOLVE) {
+            const bool mine = L.state == S_RESOLVE;
+            if (STATS) {
+                if ((threadIdx.x & 63) == 0) n.v[D_RESOLVE_PHASES]++;
+                if (mine) n.v[D_RESOLVE_LANES]++;
+            }
+            bool done = false;
+            Col value = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (mine && !fresh) resolve_lane<STATS>(sc, T, job, stack, L, n, done, value);
+            if (mine && done) store_sample(sc, job, L, value);
+            bool need = mine && (fresh || done);
+            if (need) L.state = S_IDLE;
+            while (__any(need)) {
+                unsigned long long id = 0;
+                const bool got = fetch_ids(job.queue_head, job.n_samples, need, id);
+                if (need) {
+                    if (!got) {
+                        need = false;
+                    } else if (start_sample(sc, job, id, L)) {
+                        need = false;
+                        fresh = false;
+                    }
+                }
+            }
+        }
+        // ---- hand new jobs to the marchers
+        if (push) {
+            lds_storef(&sh.job[JF_PX][owner], L.jp.x);
+            lds_storef(&sh.job[JF_PY][owner], L.jp.y);
+            lds_storef(&sh.job[JF_PZ][owner], L.jp.z);
+            lds_storef(&sh.job[JF_DX][owner], L.jd.x);
+            lds_storef(&sh.job[JF_DY][owner], L.jd.y);
+            lds_storef(&sh.job[JF_DZ][owner], L.jd.z);
+            lds_storef(&sh.job[JF_OX][owner], L.qo.x);
+            lds_storef(&sh.job[JF_OY][owner], L.qo.y);
+            lds_storef(&sh.job[JF_OZ][owner], L.qo.z);
+            lds_storef(&sh.job[JF_JULIA][owner], __uint_as_float(L.jidx));
+            lds_storef(&sh.job[JF_STATUS][owner], __uint_as_float(JOB_PENDING));
+        }
+        ring_push(sh.march, &sh.ctl[CTL_MARCH_TAIL], push, owner);
+        charge(phase == S_QUERY ? D_QUERY_CYCLES : phase == S_RESOLVE ? D_RESOLVE_CYCLES : D_T_WAIT_CYCLES);
+        if (phase == 0) {
+            __builtin_amdgcn_s_sleep(8);
+            wait_rounds++;
+            if (wait_rounds > kSpinLimit) lds_store(&sh.abort, 1u);
+        } else {
+            wait_rounds = 0;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        lds_release();
+        __hip_atomic_fetch_add(&sh.tracers_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lds_load(&sh.abort) != 0u) atomicExch(job.queue_head + 1, 1ull);
+    }
+    flush_counters<STATS>(n, job.counters);
+}
+
 // ---- per-pixel sum of the samples, in the reference's order (src/raytracer.cpp:61-110) ------------
 __global__ __launch_bounds__(256) void sum_samples_kernel(const float4* __restrict__ samples, float4* __restrict__ out,
                                                           unsigned long long n_pixels, unsigned samples_per_pixel, float inv_samples) {
@@ -1018,6 +1445,8 @@ template __global__ void trace_kernel<false, false>(const DevScene, const DevJob
 template __global__ void trace_kernel<false, true>(const DevScene, const DevJob);
 template __global__ void trace_kernel<true, false>(const DevScene, const DevJob);
 template __global__ void trace_kernel<true, true>(const DevScene, const DevJob);
+template __global__ void trace_julia_kernel<false>(const DevScene, const DevJob);
+template __global__ void trace_julia_kernel<true>(const DevScene, const DevJob);
 template __global__ void photon_kernel<false, false>(const DevScene, const DevPhotonJob);
 template __global__ void photon_kernel<false, true>(const DevScene, const DevPhotonJob);
 template __global__ void photon_kernel<true, false>(const DevScene, const DevPhotonJob);

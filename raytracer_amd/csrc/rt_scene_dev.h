@@ -175,6 +175,17 @@ struct DevPhotonJob {
     unsigned long long* counters;
 };
 
+// Shape of trace_julia_kernel's workgroup (rt_kernels.hip), shared with the launch code
+#ifndef RT_JULIA_WAVES
+#define RT_JULIA_WAVES 12
+#endif
+#ifndef RT_JULIA_MARCHERS
+#define RT_JULIA_MARCHERS 5
+#endif
+constexpr int kJuliaWaves = RT_JULIA_WAVES;              // per workgroup, a multiple of 4 (waves per SIMD = kJuliaWaves / 4)
+constexpr int kJuliaMarcherWaves = RT_JULIA_MARCHERS;
+constexpr uint32_t kJuliaStaticLdsBytes = 46 * 1024;     // upper bound of its static LDS (job table + rings)
+
 enum CounterSlot : int {
     C_PRIMARY = 0, C_SECONDARY, C_SHADOW, C_PHOTON_SEGMENTS, C_PHOTON_DEPOSITS, C_SPHERE_TESTS, C_TRIANGLE_TESTS,
     C_JULIA_QUERIES, C_JULIA_STEPS, C_JULIA_DE_ITERATIONS, C_JULIA_NORMALS, C_SHADED_HITS, C_PHONG_LIGHTS,
@@ -184,6 +195,7 @@ enum CounterSlot : int {
     D_RESOLVE_PHASES, D_RESOLVE_LANES, D_DE_WAVE_ITERS,
     D_QUERY_CYCLES, D_MARCH_CYCLES, D_NORMAL_CYCLES, D_RESOLVE_CYCLES, D_TRI_CYCLES, D_SPHERE_CYCLES,
     D_R_NODE_CYCLES, D_R_LIGHT_CYCLES, D_R_SHADOWSETUP_CYCLES, D_R_FRESNEL_CYCLES, D_R_RETURN_CYCLES, D_R_FETCH_CYCLES,
+    D_M_TAIL_CYCLES, D_M_IDLE_CYCLES, D_M_REFILL_CYCLES, D_T_WAIT_CYCLES, D_M_TAIL_BLOCKS, D_M_TAIL_LANES,
     C_COUNT
 };
 
