@@ -833,10 +833,10 @@ constexpr unsigned kJuliaQueueCap = kJuliaTracerLanes <= 512 ? 512u : 1024u;    
 static_assert(sizeof(float) * 11 * kJuliaTracerLanes + 16 * kJuliaQueueCap + 64 <= kJuliaStaticLdsBytes, "kJuliaStaticLdsBytes");
 static_assert(kJuliaQueueCap >= kJuliaTracerLanes && (kJuliaQueueCap & (kJuliaQueueCap - 1)) == 0, "ring size");
 #ifndef RT_JULIA_STEP_DIVISOR
-#define RT_JULIA_STEP_DIVISOR 3
+#define RT_JULIA_STEP_DIVISOR 2
 #endif
 #ifndef RT_JULIA_TRACER_MIN_READY
-#define RT_JULIA_TRACER_MIN_READY 24        // a tracer wave waits for this many serviceable lanes while the marchers have work
+#define RT_JULIA_TRACER_MIN_READY 12        // a tracer wave waits for this many serviceable lanes while the marchers have work
 #endif
 constexpr unsigned kSpinLimit = 1u << 24;   // polling rounds before a wave declares the launch stuck
 

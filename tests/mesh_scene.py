@@ -64,3 +64,71 @@ def write_mesh_scene(tmp_path, n_lat=48, n_lon=96, poles=False, width=160, heigh
       <phong ka="0.3" kd="0.9" ks="1.0" exponent="200"/><reflectance r="0.4"/><transmittance t="0"/><refraction iof="2.3"/></material_solid></sphere>
   </surfaces></scene>''' % (width, height, os.path.join(ROOT, "scenes", "examples", "mramor6x6.png")))
     return str(xml)
+
+
+def write_culling_scene(tmp_path, width=320, height=200):
+    """Spheres and small meshes far from the world origin seen from a distant camera: the case where
+    the reference's object-space discriminant is dominated by rounding error, which the bounding-sphere
+    and chunk culling must never turn into a different answer (slack terms of DevSphereBound /
+    DevTriChunk).  Squashed, rotated ellipsoids; one sphere encloses the camera; a light inside a sphere."""
+    box = os.path.join(ROOT, "scenes", "examples", "box.obj")
+    plane = os.path.join(ROOT, "scenes", "examples", "plane_small.obj")
+    spheres = []
+    for i in range(9):
+        x, y = (i % 3 - 1) * 7.0, (i // 3 - 1) * 5.0
+        spheres.append('''<sphere radius="%.2f"><position x="0" y="0" z="0"/><material_solid><color r="%.2f" g="%.2f" b="0.3"/>
+      <phong ka="0.3" kd="0.8" ks="1.0" exponent="%d"/><reflectance r="%s"/><transmittance t="%s"/><refraction iof="%s"/></material_solid>
+      <transform><translate x="%.1f" y="%.1f" z="%.1f"/><rotateZ theta="%d"/><scale x="%.2f" y="%.2f" z="%.2f"/><rotateY theta="%d"/></transform></sphere>''' % (
+            0.5 + 0.2 * i, 0.2 + 0.08 * i, 0.9 - 0.08 * i, 20 + 30 * i, "0.5" if i % 3 == 0 else "0", "0.7" if i % 3 == 1 else "0",
+            "1.5" if i % 3 else "2.0", 4000.0 + x, 3000.0 + y, -5000.0 - 3 * i, 17 * i, 1.0 + 0.6 * i, 1.0 / (1.0 + 0.3 * i), 0.4 + 0.2 * i, 23 * i))
+    meshes = []
+    for i in range(6):
+        meshes.append('''<mesh name="%s"><material_solid><color r="0.6" g="%.2f" b="0.2"/><phong ka="0.3" kd="0.9" ks="1.0" exponent="60"/>
+      <reflectance r="0"/><transmittance t="0"/><refraction iof="0"/></material_solid>
+      <transform><translate x="%.1f" y="%.1f" z="%.1f"/><rotateY theta="%d"/><rotateX theta="%d"/><scale x="%.2f" y="1.0" z="%.2f"/></transform></mesh>''' % (
+            box, 0.1 + 0.15 * i, 4000.0 - 9.0 + 3.5 * i, 3000.0 - 6.0 + (i % 2) * 11.0, -5004.0 - i, 31 * i, 11 * i, 0.5 + 0.3 * i, 1.5 - 0.2 * i))
+    xml = tmp_path / "culling.xml"
+    xml.write_text('''<scene output_file="culling.png"><background_color r="0.05" g="0.05" b="0.1"/>
+  <camera><position x="4000" y="3001" z="-4940"/><lookat x="4000" y="3000" z="-5004"/><up x="0" y="1" z="0"/><horizontal_fov angle="12"/>
+    <resolution horizontal="%d" vertical="%d"/><max_bounces n="4"/></camera>
+  <lights><ambient_light><color r="1" g="1" b="1"/></ambient_light>
+    <point_light><color r="0.8" g="0.8" b="0.8"/><position x="4010" y="3015" z="-4990"/></point_light>
+    <point_light><color r="0.4" g="0.4" b="0.5"/><position x="4000" y="3000" z="-5000.2"/></point_light>
+    <parallel_light><color r="0.3" g="0.3" b="0.3"/><direction x="-1" y="-1" z="-1"/></parallel_light></lights>
+  <surfaces>
+    <mesh name="%s"><material_solid><color r="0.5" g="0.5" b="0.5"/><phong ka="0.3" kd="0.9" ks="0.5" exponent="30"/>
+      <reflectance r="0"/><transmittance t="0"/><refraction iof="0"/></material_solid>
+      <transform><translate x="4000" y="2990" z="-5000"/><rotateX theta="-90"/><scale x="40" y="40" z="1"/></transform></mesh>
+    %s
+    %s
+    <sphere radius="200"><position x="0" y="0" z="0"/><material_solid><color r="0.2" g="0.2" b="0.4"/>
+      <phong ka="0.5" kd="0.5" ks="0.0" exponent="1"/><reflectance r="0"/><transmittance t="0"/><refraction iof="0"/></material_solid>
+      <transform><translate x="4000" y="3000" z="-5000"/></transform></sphere>
+  </surfaces></scene>''' % (width, height, plane, "\n    ".join(meshes), "\n    ".join(spheres)))
+    return str(xml)
+
+
+def write_two_julia_scene(tmp_path, width=120, height=90):
+    """Two Julia sets (one behind the other, one scaled and rotated) over a mirror floor with two lights:
+    queries that march one set and then the next, shadow rays with a finite maximum, ties by scene order."""
+    plane = os.path.join(ROOT, "scenes", "examples", "plane_small.obj")
+    xml = tmp_path / "two_julia.xml"
+    xml.write_text('''<scene output_file="two_julia.png"><background_color r="0.2" g="0.3" b="0.5"/>
+  <camera><position x="0" y="0.5" z="3.2"/><lookat x="0" y="0" z="0"/><up x="0" y="1" z="0"/><horizontal_fov angle="35"/>
+    <resolution horizontal="%d" vertical="%d"/><max_bounces n="3"/></camera>
+  <lights><ambient_light><color r="1" g="1" b="1"/></ambient_light>
+    <point_light><color r="0.8" g="0.8" b="0.8"/><position x="3" y="4" z="3"/></point_light>
+    <point_light><color r="0.5" g="0.4" b="0.3"/><position x="-2" y="1" z="1.5"/></point_light></lights>
+  <surfaces>
+    <julia scale="1.1" cr="-0.2" ca="0.6" cb="0.2" cc="0.2" cutplane="0.0"><position x="-0.6" y="0" z="0"/>
+      <material_solid><color r="0.8" g="0.5" b="0.2"/><phong ka="0.3" kd="0.8" ks="1.0" exponent="40"/>
+      <reflectance r="0.4"/><transmittance t="0"/><refraction iof="1.6" ec="0.5"/></material_solid></julia>
+    <mesh name="%s"><material_solid><color r="0.4" g="0.4" b="0.4"/><phong ka="0.3" kd="0.7" ks="1.0" exponent="100"/>
+      <reflectance r="0.6"/><transmittance t="0"/><refraction iof="1.5" ec="1.0"/></material_solid>
+      <transform><translate x="0" y="-1.3" z="0"/><rotateX theta="-90"/><scale x="6" y="6" z="1"/></transform></mesh>
+    <julia scale="0.9" cr="-0.291" ca="-0.399" cb="0.339" cc="0.437" cutplane="0.1"><position x="0" y="0" z="0"/>
+      <material_solid><color r="0.3" g="0.7" b="0.5"/><phong ka="0.3" kd="0.8" ks="1.0" exponent="60"/>
+      <reflectance r="0"/><transmittance t="0"/><refraction iof="0"/></material_solid>
+      <transform><translate x="0.9" y="0.1" z="-0.8"/><rotateY theta="40"/><scale x="1.2" y="0.9" z="1.0"/></transform></julia>
+  </surfaces></scene>''' % (width, height, plane))
+    return str(xml)

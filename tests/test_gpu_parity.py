@@ -402,3 +402,47 @@ def test_bvh_forced_on_the_configured_scenes():
         else:
             assert np.allclose(img, ref, rtol=1e-5, atol=1e-7), rel
     ctx.close()
+
+
+# ---- wave-level culling and the job queues of the Julia kernel ---------------------------------------
+
+from mesh_scene import write_culling_scene, write_two_julia_scene  # noqa: E402
+
+
+def test_culling_never_changes_the_answer_far_from_the_origin(tmp_path):
+    """Ellipsoids and meshes 6400 units from the world origin (the reference's object-space
+    discriminants are dominated by rounding there), a sphere around the camera, a light inside a sphere:
+    bounding-sphere and chunk culling must leave every pixel and every counter as the oracle has them."""
+    sc = capi.Scene(write_culling_scene(tmp_path), 0.0)
+    assert sc.desc.n_spheres == 10 and sc.desc.n_triangles >= 70
+    ctx = capi.Context(0)
+    ctx.set_option(capi.RT_OPT_COLLECT_STATS, 1)
+    ctx.upload(sc)
+    img, st = ctx.render()
+    ref, ost = oracle_lib.render(sc, None, threads=16)
+    assert np.array_equal(np.isnan(img), np.isnan(ref))
+    assert np.array_equal(np.nan_to_num(img).view(np.uint32), np.nan_to_num(ref).view(np.uint32))
+    for k in ("primary_rays", "secondary_rays", "shadow_rays", "sphere_tests", "triangle_tests", "shaded_hits"):
+        assert getattr(st, k) == getattr(ost, k), k
+    assert st.secondary_rays > 0 and st.shadow_rays > st.primary_rays
+    ctx.close()
+
+
+def test_two_julia_sets_through_the_job_queues(tmp_path):
+    """Queries that march one Julia set and then the next one, reflections between them and shadow rays
+    with a finite maximum, against the oracle bit for bit (tracer / marcher hand-over of trace_julia_kernel)."""
+    sc = capi.Scene(write_two_julia_scene(tmp_path), 0.0)
+    assert sc.desc.n_julias == 2
+    ctx = capi.Context(0)
+    ctx.set_option(capi.RT_OPT_COLLECT_STATS, 1)
+    ctx.upload(sc)
+    img, st = ctx.render()
+    ref, ost = oracle_lib.render(sc, None, threads=16)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    for k in ("primary_rays", "secondary_rays", "shadow_rays", "julia_queries", "julia_steps", "julia_normals", "shaded_hits"):
+        assert getattr(st, k) == getattr(ost, k), k
+    assert st.julia_normals > 0 and st.secondary_rays > 0
+    # a second render on the same context gives the same picture (queues start clean every launch)
+    img2, _ = ctx.render()
+    assert np.array_equal(img.view(np.uint32), img2.view(np.uint32))
+    ctx.close()
