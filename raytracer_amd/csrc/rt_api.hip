@@ -18,7 +18,7 @@
 #include "rt_scene_dev.h"
 
 namespace rtd {
-template <bool HAS_JULIA, bool STATS>
+template <bool STATS>
 __global__ void trace_kernel(const DevScene sc, const DevJob job);
 template <bool STATS>
 __global__ void trace_julia_kernel(const DevScene sc, const DevJob job);
@@ -180,7 +180,7 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
         blocks = static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(ctx->n_cus), needed ? needed : 1));
         lanes = static_cast<uint64_t>(blocks) * kJuliaTracerLanesHost;
     } else {
-        rc = stats ? persistent_grid(ctx, trace_kernel<false, true>, job.n_samples, &blocks, lds) : persistent_grid(ctx, trace_kernel<false, false>, job.n_samples, &blocks, lds);
+        rc = stats ? persistent_grid(ctx, trace_kernel<true>, job.n_samples, &blocks, lds) : persistent_grid(ctx, trace_kernel<false>, job.n_samples, &blocks, lds);
         if (rc != RT_OK) return rc;
         lanes = static_cast<uint64_t>(blocks) * 256;
     }
@@ -202,8 +202,8 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
         if (stats) hipLaunchKernelGGL((trace_julia_kernel<true>), dim3(blocks), dim3(kJuliaBlockThreads), lds, stream, dev, job);
         else hipLaunchKernelGGL((trace_julia_kernel<false>), dim3(blocks), dim3(kJuliaBlockThreads), lds, stream, dev, job);
     } else {
-        if (stats) hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(256), lds, stream, dev, job);
-        else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(256), lds, stream, dev, job);
+        if (stats) hipLaunchKernelGGL((trace_kernel<true>), dim3(blocks), dim3(256), lds, stream, dev, job);
+        else hipLaunchKernelGGL((trace_kernel<false>), dim3(blocks), dim3(256), lds, stream, dev, job);
     }
     RT_HIP_TRY(ctx, hipGetLastError());
     if (job.samples_per_pixel > 1) {

@@ -14,9 +14,8 @@
 //   * the expensive operation — one ray against every scene object — is a single wave-uniform
 //     object loop shared by nearest-hit, shadow and photon queries: geometry records are read with
 //     scalar loads into SGPRs, every lane with a pending query of any kind takes part;
-//   * Julia sets are marched outside that loop, one distance-estimator call per scheduling step,
-//     and a wave-level scheduler always runs the phase (query / march / normal / resolve) that the
-//     most lanes are waiting for;
+//   * Julia sets are marched outside that loop by dedicated marcher waves fed through LDS rings
+//     (trace_julia_kernel);
 //   * per-sample results go to a [sample][pixel] buffer in HBM and are summed per pixel in the
 //     reference's order by a second kernel.
 #include <hip/hip_runtime.h>
@@ -33,15 +32,9 @@ namespace rtd {
 #define RT_TRI_GROUP 4
 #endif
 static_assert(RT_TRI_GROUP == kTriChunk, "the triangle loop steps by one chunk of tri_chunks");
-#ifndef RT_SERVICE_THRESHOLD
-#define RT_SERVICE_THRESHOLD 16   // lanes waiting outside the march before it is interrupted
-#endif
-#ifndef RT_TRACE_WAVES_JULIA
-#define RT_TRACE_WAVES_JULIA 2
-#endif
 
 enum QueryKind : int { Q_TRACE = 0, Q_SHADOW = 1, Q_PHOTON = 2 };
-enum LaneState : int { S_IDLE = 0, S_QUERY = 1, S_MARCH = 2, S_NORMAL = 3, S_RESOLVE = 4 };
+enum LaneState : int { S_IDLE = 0, S_QUERY = 1, S_WAIT = 2 /* a Julia job of this lane is with the marchers */, S_RESOLVE = 4 };
 
 constexpr int kFrameFields = 11;
 constexpr unsigned kNoTriangle = 0xffffffffu;
@@ -340,22 +333,6 @@ RT_DEV void accept_julia_hit(Lane& L, const HitRec& h, const DevJulia& j, const 
         if (!nearer) return;
     }
     accept_hit(L, h, j.object, m.transmittance, m.refr_norm);
-}
-
-// Finds the next Julia set (index >= from) whose bounding sphere the current query ray enters and
-// puts the lane into the march state for it; without one the query is complete.
-template <bool STATS>
-RT_DEV void enter_next_julia(const DevScene& sc, Lane& L, unsigned from, Counters& n) {
-    L.state = S_RESOLVE;
-    for (unsigned k = from; k < sc.n_julias; k++) {
-        bump<STATS>(n, C_JULIA_QUERIES);
-        if (julia_enter(sc.julias[k], L.qo, L.qd, L.jp, L.jd)) {
-            L.jidx = k;
-            L.jstep = 0;
-            L.state = S_MARCH;
-            break;
-        }
-    }
 }
 
 RT_DEV void begin_query(Lane& L, V3 o, V3 d, float maxd, int kind) {
@@ -679,9 +656,9 @@ RT_DEV void flush_counters(const Counters& n, unsigned long long* out) {
     }
 }
 
-// ---- the render kernel ------------------------------------------------------------------------------
-template <bool HAS_JULIA, bool STATS>
-__global__ __launch_bounds__(256, HAS_JULIA ? RT_TRACE_WAVES_JULIA : RT_TRACE_WAVES_PER_SIMD) void trace_kernel(const DevScene sc_global, const DevJob job) {
+// ---- the render kernel (scenes without Julia sets) ----------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(const DevScene sc_global, const DevJob job) {
     // With a small scene the shading tables are read from an LDS copy of the shade blob (latency
     // ~64 cycles instead of an L2 round trip per dependent load); the wave-uniform geometry reads
     // keep using the HBM tables (scalar loads).
@@ -711,77 +688,23 @@ __global__ __launch_bounds__(256, HAS_JULIA ? RT_TRACE_WAVES_JULIA : RT_TRACE_WA
     bool fresh = true;         // lane holds no sample yet
 
     for (;;) {
-        // ---- pick the phase most lanes are waiting for --------------------------------------------
-        int phase;
-        if (HAS_JULIA) {
-            const int n_query = __popcll(__ballot(L.state == S_QUERY));
-            const int n_march = __popcll(__ballot(L.state == S_MARCH));
-            const int n_normal = __popcll(__ballot(L.state == S_NORMAL));
-            const int n_resolve = __popcll(__ballot(L.state == S_RESOLVE));
-            if (n_query + n_march + n_normal + n_resolve == 0) break;
-            // Marching is ~90 % of the work, so keep the march phases full: as soon as enough lanes
-            // wait in the cheap phases they are serviced (largest group first) and rejoin the march.
-            phase = S_MARCH;
-            if (n_march == 0 || n_query + n_normal + n_resolve >= RT_SERVICE_THRESHOLD) {
-                int best = -1;
-                if (n_normal > best && n_normal > 0) { best = n_normal; phase = S_NORMAL; }
-                if (n_resolve > best && n_resolve > 0) { best = n_resolve; phase = S_RESOLVE; }
-                if (n_query > best && n_query > 0) { best = n_query; phase = S_QUERY; }
-            }
-        } else {
-            // without Julia sets every lane alternates query -> resolve in lockstep
-            const bool any_query = __any(L.state == S_QUERY);
-            const bool any_resolve = __any(L.state == S_RESOLVE);
-            if (!any_query && !any_resolve) break;
-            phase = any_query ? S_QUERY : S_RESOLVE;
-        }
+        // every lane alternates query -> resolve in lockstep
+        const bool any_query = __any(L.state == S_QUERY);
+        const bool any_resolve = __any(L.state == S_RESOLVE);
+        if (!any_query && !any_resolve) break;
+        const int phase = any_query ? S_QUERY : S_RESOLVE;
 
         long long t_phase = 0, t_fetch_outer = 0;
         if (STATS) {
             t_phase = clock64();
-            const int base = phase == S_QUERY ? D_QUERY_PHASES : phase == S_MARCH ? D_MARCH_PHASES : phase == S_NORMAL ? D_NORMAL_PHASES : D_RESOLVE_PHASES;
+            const int base = phase == S_QUERY ? D_QUERY_PHASES : D_RESOLVE_PHASES;
             if ((threadIdx.x & 63) == 0) n.v[base]++;
             if (L.state == phase) n.v[base + 1]++;
         }
         if (phase == S_QUERY) {
             const bool mine = L.state == S_QUERY;
             query_objects<STATS>(sc, L, mine, n);
-            if (mine) {
-                L.state = S_RESOLVE;
-                if (HAS_JULIA && L.qactive) enter_next_julia<STATS>(sc, L, 0, n);
-            }
-        } else if (HAS_JULIA && phase == S_MARCH) {
-            unsigned long long my_iters = 0;
-            if (L.state == S_MARCH) {
-                const DevJulia& j = sc.julias[L.jidx];
-                bump<STATS>(n, C_JULIA_STEPS);
-                unsigned long long iters = 0;
-                const int r = julia_step<STATS>(j, L.jp, L.jd, L.jstep, iters);
-                bump<STATS>(n, C_JULIA_DE_ITERATIONS, iters);
-                my_iters = iters;
-                if (r == 1) L.state = S_NORMAL;
-                if (r == 2) enter_next_julia<STATS>(sc, L, L.jidx + 1, n);
-            }
-            if (STATS) {
-                unsigned long long wmax = my_iters;
-                for (int off = 32; off > 0; off >>= 1) {
-                    const unsigned long long o = __shfl_xor(wmax, off);
-                    wmax = o > wmax ? o : wmax;
-                }
-                if ((threadIdx.x & 63) == 0) n.v[D_DE_WAVE_ITERS] += wmax * 64ull;
-            }
-        } else if (HAS_JULIA && phase == S_NORMAL) {
-            if (L.state == S_NORMAL) {
-                const DevJulia& j = sc.julias[L.jidx];
-                bump<STATS>(n, C_JULIA_NORMALS);
-                unsigned long long iters = 0;
-                HitRec h;
-                // Julia::intersect ignores max_distance until this final check (src/objects.cpp:236)
-                const float limit = L.qkind == Q_SHADOW ? L.qmax : kInfinite;
-                if (julia_finish<STATS>(j, L.qo, L.jp, L.jd, limit, h, iters)) accept_julia_hit(L, h, j, T.materials[j.material]);
-                bump<STATS>(n, C_JULIA_DE_ITERATIONS, iters);
-                if (L.qactive) enter_next_julia<STATS>(sc, L, L.jidx + 1, n); else L.state = S_RESOLVE;
-            }
+            if (mine) L.state = S_RESOLVE;
         } else {   // S_RESOLVE
             const bool mine = L.state == S_RESOLVE;
             bool done = false;
@@ -807,7 +730,7 @@ __global__ __launch_bounds__(256, HAS_JULIA ? RT_TRACE_WAVES_JULIA : RT_TRACE_WA
         }
         if (STATS && phase == S_RESOLVE && (threadIdx.x & 63) == 0) n.v[D_R_FETCH_CYCLES] += static_cast<unsigned long long>(clock64() - t_fetch_outer);
         if (STATS && (threadIdx.x & 63) == 0) {
-            const int slot = phase == S_QUERY ? D_QUERY_CYCLES : phase == S_MARCH ? D_MARCH_CYCLES : phase == S_NORMAL ? D_NORMAL_CYCLES : D_RESOLVE_CYCLES;
+            const int slot = phase == S_QUERY ? D_QUERY_CYCLES : D_RESOLVE_CYCLES;
             n.v[slot] += static_cast<unsigned long long>(clock64() - t_phase);
         }
     }
@@ -1110,7 +1033,6 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
     L.jstep = 0;
     bool fresh = true;
     unsigned wait_rounds = 0;
-    // S_MARCH here means: a job of this lane is with the marchers
     long long t_mark = STATS ? clock64() : 0;
     auto charge = [&](int slot) {
         if (STATS) {
@@ -1123,7 +1045,7 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
         if (lds_load(&sh.abort) != 0u) break;
         // ---- collect finished jobs (Julia::intersect's last checks and the acceptance rule)
         bool push = false;
-        if (L.state == S_MARCH) {
+        if (L.state == S_WAIT) {
             const unsigned st = __float_as_uint(lds_loadf(&sh.job[JF_STATUS][owner]));
             if (st != JOB_PENDING) {
                 lds_acquire();
@@ -1146,7 +1068,7 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
                         bump<STATS>(n, C_JULIA_QUERIES);
                         if (julia_enter(sc.julias[k], L.qo, L.qd, L.jp, L.jd)) {
                             L.jidx = k;
-                            L.state = S_MARCH;
+                            L.state = S_WAIT;
                             push = true;
                             break;
                         }
@@ -1156,7 +1078,7 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
         }
         const int n_query = __popcll(__ballot(L.state == S_QUERY));
         const int n_resolve = __popcll(__ballot(L.state == S_RESOLVE));
-        const int n_wait = __popcll(__ballot(L.state == S_MARCH));
+        const int n_wait = __popcll(__ballot(L.state == S_WAIT));
         int phase = 0;
         if (n_query + n_resolve == 0) {
             if (n_wait == 0) break;
@@ -1177,7 +1099,7 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
                         bump<STATS>(n, C_JULIA_QUERIES);
                         if (julia_enter(sc.julias[k], L.qo, L.qd, L.jp, L.jd)) {
                             L.jidx = k;
-                            L.state = S_MARCH;
+                            L.state = S_WAIT;
                             push = true;
                             break;
                         }
@@ -1441,10 +1363,8 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float4* __restrict_
 }
 
 // explicit instantiations used by rt_api.hip
-template __global__ void trace_kernel<false, false>(const DevScene, const DevJob);
-template __global__ void trace_kernel<false, true>(const DevScene, const DevJob);
-template __global__ void trace_kernel<true, false>(const DevScene, const DevJob);
-template __global__ void trace_kernel<true, true>(const DevScene, const DevJob);
+template __global__ void trace_kernel<false>(const DevScene, const DevJob);
+template __global__ void trace_kernel<true>(const DevScene, const DevJob);
 template __global__ void trace_julia_kernel<false>(const DevScene, const DevJob);
 template __global__ void trace_julia_kernel<true>(const DevScene, const DevJob);
 template __global__ void photon_kernel<false, false>(const DevScene, const DevPhotonJob);
