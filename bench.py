@@ -161,8 +161,10 @@ def main():
     w, h = scene.width, scene.height
     n_pix = w * h
     frame = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
-    frame8 = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
-    gathered = [torch.empty_like(frame8) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # two RGBA8 frames: the gather of step i runs on RCCL's stream while step i+1 renders
+    frame8 = [torch.empty((h, w, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+    gathered = [[torch.empty_like(frame8[0]) for _ in range(world)] for _ in range(2)] if (world > 1 and rank == 0) else [None, None]
+    pending = [None, None]
     stream = torch.cuda.current_stream().cuda_stream
     has_photons = scene.desc.photon_steps > 0
 
@@ -182,12 +184,25 @@ def main():
     stats = {k: v + pst.as_dict()[k] for k, v in rst.as_dict().items() if k != "kernel_ms"}
     rays_per_step = stats["primary_rays"] + stats["secondary_rays"] + stats["shadow_rays"] + stats["photon_segments"]
     flops_per_step = algorithmic_flops(stats)
-    ctx.set_option(capi.RT_OPT_COLLECT_STATS, 0)
+    flops_note = "algorithmic flops = counts of the reference's formulation (scan over all objects, shade once) x bench.py:FLOPS"
     if args.bvh_min is None:
         ctx.set_option(capi.RT_OPT_BVH_MIN_TRIANGLES, capi.RT_DEFAULT_BVH_MIN_TRIANGLES)
         ctx.upload(scene)
+        # a scene whose long triangle runs go through the BVH is priced at the work the traversal executes
+        # (node visits and leaf tests): against a scan of 10^5 triangles per ray the ratio would say nothing
+        ctx.render_device(frame.data_ptr(), stream)
+        torch.cuda.synchronize()
+        executed = ctx.fetch_stats().as_dict()
+        if executed.get("bvh_node_visits", 0) > 0:
+            flops_per_step = algorithmic_flops({k: v + pst.as_dict().get(k, 0) for k, v in executed.items() if k != "kernel_ms"})
+            flops_note = "BVH scene: flops of the executed traversal (node visits, leaf tests) x bench.py:FLOPS"
+    ctx.set_option(capi.RT_OPT_COLLECT_STATS, 0)
 
-    def step(events=None):
+    def step(i, events=None):
+        buf = i % 2
+        if pending[buf] is not None:
+            pending[buf].wait()          # the frame gathered two steps ago has left this buffer
+            pending[buf] = None
         if has_photons:
             ctx.photon_generate_device(stream)
         if events is not None:
@@ -195,22 +210,26 @@ def main():
         ctx.render_device(frame.data_ptr(), stream)
         if events is not None:
             events[1].record()
-        ctx.quantize_device(frame.data_ptr(), frame8.data_ptr(), 1.0, n_pix, stream)
+        ctx.quantize_device(frame.data_ptr(), frame8[buf].data_ptr(), 1.0, n_pix, stream)
         if world > 1:
-            dist.gather(frame8, gathered, dst=0)
+            pending[buf] = dist.gather(frame8[buf], gathered[buf], dst=0, async_op=True)
 
     def fence():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     fence()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(events[i])
+        step(i, events[i])
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -228,12 +247,12 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "scene": rel, "t": t, "rays_per_frame": rays_per_step,
                        "frames_per_step": world, "sec_per_frame": elapsed / args.steps,
-                       "parallelism": "frames sharded over ranks, RGBA8 frames gathered to rank 0 over RCCL" if world > 1 else "1 GPU"},
+                       "parallelism": "frames sharded over ranks, RGBA8 frames gathered to rank 0 over RCCL (gather of a step overlaps the next step's render; all gathers complete inside the timed region)" if world > 1 else "1 GPU"},
             "roofline": {"bound": "valu", "kernel": "trace_kernel", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": measured_traffic(args.workload),
                          "frac_of_unfused_issue_ceiling": achieved / ISSUE_CEILING_TFLOPS,
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops_per_step,
-                         "note": "FP32 VALU bound (no HBM or MFMA roofline applies: scene is KBs, nothing is a contraction); see DESIGN.md"},
+                         "note": "FP32 VALU bound (no HBM or MFMA roofline applies: scene is KBs, nothing is a contraction); " + flops_note + "; see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene, rays_per_step)
