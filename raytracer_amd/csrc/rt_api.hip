@@ -31,7 +31,7 @@ __global__ void mul_add_kernel(float* acc, const float* src, float factor, unsig
 __global__ void quantize_kernel(const float4* rgba, uchar4* out, float gain, unsigned long long n);
 hipError_t build_triangle_bvh(const DevTriTest* tris, uint32_t first, uint32_t n, DevBvhNode* nodes);
 constexpr int kFrameFieldsHost = 11;
-constexpr size_t kMaxLdsBlobBytes = 36 * 1024;   // keeps 4 blocks per CU within the 160 KB LDS
+constexpr size_t kMaxLdsBlobBytes = 28 * 1024;   // + 11 KB of frame tops: keeps 4 blocks per CU within the 160 KB LDS
 constexpr size_t kMaxLdsBlobBytesJulia = 64 * 1024 - kJuliaStaticLdsBytes;   // trace_julia_kernel: blob + its queues stay under 64 KB
 constexpr int kJuliaBlockThreads = kJuliaWaves * 64, kJuliaTracerLanesHost = (kJuliaWaves - kJuliaMarcherWaves) * 64;
 }  // namespace rtd
@@ -143,6 +143,15 @@ void make_job(const rt_ctx* ctx, const rt_bands* bands, DevJob* job) {
     job->dof_seed = ctx->dof_seed;
 }
 
+// Ids a wave reserves per atomic: at least 16 reservations per wave for balance, whole 8x8 tiles.
+uint32_t id_chunk_for(uint64_t items, uint64_t lanes) {
+    const uint64_t per_wave = items / std::max<uint64_t>(1, lanes / 64);
+    uint64_t c = (per_wave / 16) & ~uint64_t(63);
+    if (c < 64) c = 64;
+    if (c > 1024) c = 1024;
+    return static_cast<uint32_t>(c);
+}
+
 template <typename K>
 int persistent_grid(rt_ctx* ctx, K kernel, uint64_t work_items, int* blocks, size_t lds_bytes = 0) {
     int per_cu = 0;
@@ -192,6 +201,7 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
         job.samples = static_cast<float4*>(ctx->samples.ptr);
     }
     job.out = d_out;
+    job.id_chunk = 1;   // see fetch_ids
     job.stack = static_cast<float*>(ctx->stack.ptr);
     job.queue_head = ctx->d_queue;
     job.counters = ctx->d_counters;
@@ -239,22 +249,24 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream) {
         const bool stats = ctx->collect_stats;
         int blocks = 0;
         int rc;
-        if (julia) rc = stats ? persistent_grid(ctx, photon_kernel<true, true>, job.n_roots, &blocks) : persistent_grid(ctx, photon_kernel<true, false>, job.n_roots, &blocks);
-        else rc = stats ? persistent_grid(ctx, photon_kernel<false, true>, job.n_roots, &blocks) : persistent_grid(ctx, photon_kernel<false, false>, job.n_roots, &blocks);
+        const size_t lds = ctx->dev.shade_blob_in_lds ? ctx->dev.shade_blob_bytes : 0;
+        if (julia) rc = stats ? persistent_grid(ctx, photon_kernel<true, true>, job.n_roots, &blocks, lds) : persistent_grid(ctx, photon_kernel<true, false>, job.n_roots, &blocks, lds);
+        else rc = stats ? persistent_grid(ctx, photon_kernel<false, true>, job.n_roots, &blocks, lds) : persistent_grid(ctx, photon_kernel<false, false>, job.n_roots, &blocks, lds);
         if (rc != RT_OK) return rc;
         const uint64_t lanes = static_cast<uint64_t>(blocks) * 256;
         rc = grow(ctx, ctx->stack, lanes * (ctx->dev.max_bounces + 1) * kFrameFieldsHost * sizeof(float));
         if (rc != RT_OK) return rc;
         job.stack = static_cast<float*>(ctx->stack.ptr);
+        job.id_chunk = id_chunk_for(job.n_roots, lanes);
         job.queue_head = ctx->d_queue;
         job.counters = ctx->d_counters;
         RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), stream));
         if (julia) {
-            if (stats) hipLaunchKernelGGL((photon_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, ctx->dev, job);
-            else hipLaunchKernelGGL((photon_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, ctx->dev, job);
+            if (stats) hipLaunchKernelGGL((photon_kernel<true, true>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
+            else hipLaunchKernelGGL((photon_kernel<true, false>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
         } else {
-            if (stats) hipLaunchKernelGGL((photon_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, ctx->dev, job);
-            else hipLaunchKernelGGL((photon_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, ctx->dev, job);
+            if (stats) hipLaunchKernelGGL((photon_kernel<false, true>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
+            else hipLaunchKernelGGL((photon_kernel<false, false>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
         }
         RT_HIP_TRY(ctx, hipGetLastError());
     }

@@ -95,15 +95,18 @@ struct Lane {
     unsigned n_obj;
     float acc[3], matcol[3];
     unsigned li;
-    // the newest frame of the DFS stack is kept in registers; HBM only holds the frames below it
+    // the newest frame of the DFS stack is kept in LDS; HBM only holds the frames below it
     // (written when a deeper frame is pushed, prefetched back when the top is popped)
-    float top[11];
+    float* top_base;         // this lane's column of the workgroup's LDS array [field][lane] (11 KB per 256 lanes;
+    unsigned top_stride;     // in registers it was the first thing the compiler spilled to scratch)
     // sample
     unsigned sp;             // frames on the stack == depth of the current node
     float wavelength;
     int hue;                 // -1 without dispersion
     unsigned long long out_slot;
 };
+
+RT_DEV float& top_of(Lane& L, int c) { return L.top_base[c * L.top_stride]; }
 
 template <bool STATS>
 RT_DEV void bump(Counters& n, int slot, unsigned long long by = 1) {
@@ -355,19 +358,44 @@ struct FrameRef {
 };
 
 // ---- sample queue ---------------------------------------------------------------------------------
-// Lanes with `need` set get consecutive sample ids (one atomic per wave and call).
-RT_DEV bool fetch_ids(unsigned long long* head, unsigned long long limit, bool need, unsigned long long& id) {
+// Lanes with `need` set get consecutive sample ids.  A wave reserves at least `chunk` ids from the
+// global counter at a time and hands them out locally.  The photon pass (short, uniform units) takes
+// chunks of hundreds: with one atomic per refill it spent 87 % of its wave cycles waiting for the
+// single counter (profiles/r01_c5_pmc_summary.txt; 1.75 -> 1.15 ms).  The trace kernels reserve
+// exactly what the idle lanes need (chunk = 1): their units vary by orders of magnitude and ids
+// parked in a slow wave cost more at the end of the frame than the atomics do (measured: C3 +18 %).
+struct WaveIds {
+    unsigned long long next, end;   // wave-uniform
+};
+RT_DEV bool fetch_ids(unsigned long long* head, unsigned long long limit, unsigned chunk, WaveIds& w, bool need, unsigned long long& id) {
     const unsigned long long mask = __ballot(need);
-    if (!need) return false;
+    if (mask == 0ull) return false;
     const int lane = threadIdx.x & 63;
-    const int leader = __ffsll(static_cast<long long>(mask)) - 1;
-    const unsigned cnt = __popcll(mask);
-    unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd(head, static_cast<unsigned long long>(cnt));
-    base = __shfl(base, leader);
     const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
-    id = base + rank;
-    return id < limit;
+    const unsigned cnt = __popcll(mask);
+    unsigned served = 0;
+    bool got = false;
+    while (served < cnt) {
+        if (w.next >= w.end) {
+            if (w.end >= limit && w.end != 0ull) break;   // the queue ran dry earlier
+            const unsigned long long want = chunk > cnt - served ? chunk : cnt - served;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(head, want);
+            base = __shfl(base, 0);
+            w.next = base < limit ? base : limit;
+            w.end = base + want < limit ? base + want : limit;
+            if (w.next >= w.end) break;
+        }
+        const unsigned long long avail = w.end - w.next;
+        const unsigned take = avail < cnt - served ? static_cast<unsigned>(avail) : cnt - served;
+        if (need && rank >= served && rank < served + take) {
+            id = w.next + (rank - served);
+            got = true;
+        }
+        w.next += take;
+        served += take;
+    }
+    return got;
 }
 
 RT_DEV unsigned hash_u32(unsigned x) {
@@ -583,20 +611,20 @@ RT_DEV void resolve_lane(const DevScene& sc, const ShadeTables& T, const DevJob&
                     const unsigned f = L.sp;
                     if (f > 0) {
 #pragma unroll
-                        for (int c = 0; c < kFrameFields; c++) stack.at(f - 1, c) = L.top[c];   // spill the old top
+                        for (int c = 0; c < kFrameFields; c++) stack.at(f - 1, c) = top_of(L, c);   // spill the old top
                     }
-                    L.top[0] = L.acc[0];
-                    L.top[1] = L.acc[1];
-                    L.top[2] = L.acc[2];
-                    L.top[3] = kr;
-                    L.top[4] = mo.x;
-                    L.top[5] = mo.y;
-                    L.top[6] = mo.z;
-                    L.top[7] = md.x;
-                    L.top[8] = md.y;
-                    L.top[9] = md.z;
+                    top_of(L, 0) = L.acc[0];
+                    top_of(L, 1) = L.acc[1];
+                    top_of(L, 2) = L.acc[2];
+                    top_of(L, 3) = kr;
+                    top_of(L, 4) = mo.x;
+                    top_of(L, 5) = mo.y;
+                    top_of(L, 6) = mo.z;
+                    top_of(L, 7) = md.x;
+                    top_of(L, 8) = md.y;
+                    top_of(L, 9) = md.z;
                     // flags: bit0 = the child now in flight is the reflection, bit1 = reflection still to do
-                    L.top[10] = __uint_as_float(refr_ok ? (want_refl ? 2u : 0u) : 1u);
+                    top_of(L, 10) = __uint_as_float(refr_ok ? (want_refl ? 2u : 0u) : 1u);
                     L.sp = f + 1;
                     if (refr_ok) begin_query(L, ro, rd, kInfinite, Q_TRACE); else begin_query(L, mo, md, kInfinite, Q_TRACE);
                     descended = true;
@@ -621,22 +649,22 @@ RT_DEV void resolve_lane(const DevScene& sc, const ShadeTables& T, const DevJob&
             return;
         }
         const unsigned f = L.sp - 1;
-        const unsigned flags = __float_as_uint(L.top[10]);
-        const float kr = L.top[3];
+        const unsigned flags = __float_as_uint(top_of(L, 10));
+        const float kr = top_of(L, 3);
         const float w = (flags & 1u) ? kr : 1.0f - kr;
         float acc[3];
-        for (int c = 0; c < 3; c++) acc[c] = L.top[c] + val[c] * w;
+        for (int c = 0; c < 3; c++) acc[c] = top_of(L, c) + val[c] * w;
         if (flags & 2u) {
             // refraction child done, reflection child next
-            for (int c = 0; c < 3; c++) L.top[c] = acc[c];
-            L.top[10] = __uint_as_float(1u);
-            begin_query(L, v3(L.top[4], L.top[5], L.top[6]), v3(L.top[7], L.top[8], L.top[9]), kInfinite, Q_TRACE);
+            for (int c = 0; c < 3; c++) top_of(L, c) = acc[c];
+            top_of(L, 10) = __uint_as_float(1u);
+            begin_query(L, v3(top_of(L, 4), top_of(L, 5), top_of(L, 6)), v3(top_of(L, 7), top_of(L, 8), top_of(L, 9)), kInfinite, Q_TRACE);
             mark<STATS>(n, t_sec, D_R_RETURN_CYCLES);
             return;
         }
         if (f > 0) {
 #pragma unroll
-            for (int c = 0; c < kFrameFields; c++) L.top[c] = stack.at(f - 1, c);   // prefetch the new top
+            for (int c = 0; c < kFrameFields; c++) top_of(L, c) = stack.at(f - 1, c);   // prefetch the new top
         }
         L.sp = f;
         val[0] = acc[0];
@@ -680,12 +708,16 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
     const FrameRef stack = {job.stack + gid, grid_lanes};
 
     Lane L;
+    __shared__ float top_store[kFrameFields * 256];
+    L.top_base = top_store + threadIdx.x;
+    L.top_stride = 256;
     L.state = S_RESOLVE;       // "resolve" of a lane without a sample = fetch one
     L.qkind = -1;
     L.sp = 0;
     L.jidx = 0;
     L.jstep = 0;
     bool fresh = true;         // lane holds no sample yet
+    WaveIds wave_ids = {0ull, 0ull};
 
     for (;;) {
         // every lane alternates query -> resolve in lockstep
@@ -717,7 +749,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
             // refill from the queue; padding lanes of edge tiles simply ask again
             while (__any(need)) {
                 unsigned long long id = 0;
-                const bool got = fetch_ids(job.queue_head, job.n_samples, need, id);
+                const bool got = fetch_ids(job.queue_head, job.n_samples, job.id_chunk, wave_ids, need, id);
                 if (need) {
                     if (!got) {
                         need = false;   // queue is exhausted: this lane stays idle
@@ -753,7 +785,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
 // Queues, job records and results never leave LDS; HBM only sees the sample buffer and frame stacks.
 constexpr int kJuliaTracerLanes = (kJuliaWaves - kJuliaMarcherWaves) * 64;   // owners per workgroup
 constexpr unsigned kJuliaQueueCap = kJuliaTracerLanes <= 512 ? 512u : 1024u;    // an owner has at most one job in flight
-static_assert(sizeof(float) * 11 * kJuliaTracerLanes + 16 * kJuliaQueueCap + 64 <= kJuliaStaticLdsBytes, "kJuliaStaticLdsBytes");
+static_assert(sizeof(float) * (11 + 11) * kJuliaTracerLanes + 16 * kJuliaQueueCap + 64 <= kJuliaStaticLdsBytes, "kJuliaStaticLdsBytes");
 static_assert(kJuliaQueueCap >= kJuliaTracerLanes && (kJuliaQueueCap & (kJuliaQueueCap - 1)) == 0, "ring size");
 #ifndef RT_JULIA_STEP_DIVISOR
 #define RT_JULIA_STEP_DIVISOR 2
@@ -761,7 +793,7 @@ static_assert(kJuliaQueueCap >= kJuliaTracerLanes && (kJuliaQueueCap & (kJuliaQu
 #ifndef RT_JULIA_TRACER_MIN_READY
 #define RT_JULIA_TRACER_MIN_READY 12        // a tracer wave waits for this many serviceable lanes while the marchers have work
 #endif
-constexpr unsigned kSpinLimit = 1u << 24;   // polling rounds before a wave declares the launch stuck
+constexpr unsigned kSpinLimit = 1u << 26;   // polling rounds before a wave declares the launch stuck
 
 enum JobField : int { JF_PX = 0, JF_PY, JF_PZ, JF_DX, JF_DY, JF_DZ, JF_OX, JF_OY, JF_OZ, JF_JULIA, JF_STATUS, JF_COUNT };
 enum JobStatus : unsigned { JOB_PENDING = 0u, JOB_MISS = 1u, JOB_HIT = 2u };
@@ -1026,12 +1058,16 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
     const unsigned long long gid = static_cast<unsigned long long>(blockIdx.x) * kJuliaTracerLanes + owner;
     const FrameRef stack = {job.stack + gid, grid_lanes};
     Lane L;
+    __shared__ float top_store[kFrameFields * kJuliaTracerLanes];
+    L.top_base = top_store + owner;
+    L.top_stride = kJuliaTracerLanes;
     L.state = S_RESOLVE;       // "resolve" of a lane without a sample = fetch one
     L.qkind = -1;
     L.sp = 0;
     L.jidx = 0;
     L.jstep = 0;
     bool fresh = true;
+    WaveIds wave_ids = {0ull, 0ull};
     unsigned wait_rounds = 0;
     long long t_mark = STATS ? clock64() : 0;
     auto charge = [&](int slot) {
@@ -1120,7 +1156,7 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
             if (need) L.state = S_IDLE;
             while (__any(need)) {
                 unsigned long long id = 0;
-                const bool got = fetch_ids(job.queue_head, job.n_samples, need, id);
+                const bool got = fetch_ids(job.queue_head, job.n_samples, job.id_chunk, wave_ids, need, id);
                 if (need) {
                     if (!got) {
                         need = false;
@@ -1190,18 +1226,29 @@ __global__ __launch_bounds__(256) void photon_kernel(const DevScene sc, const De
     const unsigned long long gid = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     const FrameRef stack = {job.stack + gid, grid_lanes};
 
-    const ShadeTables T = tables_of(sc, sc.shade_blob);
+    // shading tables from LDS when they fit (as in trace_kernel)
+    extern __shared__ __align__(16) unsigned char lds_blob[];
+    const unsigned char* table_base = sc.shade_blob;
+    if (sc.shade_blob_in_lds) {
+        for (unsigned i = threadIdx.x * 16u; i < sc.shade_blob_bytes; i += 256u * 16u) {
+            *reinterpret_cast<uint4*>(lds_blob + i) = *reinterpret_cast<const uint4*>(sc.shade_blob + i);
+        }
+        __syncthreads();
+        table_base = lds_blob;
+    }
+    const ShadeTables T = tables_of(sc, table_base);
     Lane L;
     L.state = S_IDLE;
     L.sp = 0;
     float rad[4] = {0, 0, 0, 0};
     unsigned depth = 0;
     bool need = true;
+    WaveIds wave_ids = {0ull, 0ull};
     for (;;) {
         // refill idle lanes with new roots
         while (__any(need)) {
             unsigned long long id = 0;
-            const bool got = fetch_ids(job.queue_head, job.n_roots, need, id);
+            const bool got = fetch_ids(job.queue_head, job.n_roots, job.id_chunk, wave_ids, need, id);
             if (need) {
                 need = false;
                 if (got) {

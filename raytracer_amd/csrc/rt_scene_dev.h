@@ -157,6 +157,7 @@ struct DevJob {
     unsigned long long* queue_head;
     unsigned long long* counters;// rt_stats words (only touched when STATS)
     uint32_t dof_seed;
+    uint32_t id_chunk;           // sample ids a wave reserves per atomic (multiple of 64)
 };
 
 // Photon emission job (src/photonmap.cpp:38-57)
@@ -173,6 +174,7 @@ struct DevPhotonJob {
     float* stack;
     unsigned long long* queue_head;
     unsigned long long* counters;
+    uint32_t id_chunk;              // root ids a wave reserves per atomic
 };
 
 // Shape of trace_julia_kernel's workgroup (rt_kernels.hip), shared with the launch code
@@ -184,7 +186,7 @@ struct DevPhotonJob {
 #endif
 constexpr int kJuliaWaves = RT_JULIA_WAVES;              // per workgroup, a multiple of 4 (waves per SIMD = kJuliaWaves / 4)
 constexpr int kJuliaMarcherWaves = RT_JULIA_MARCHERS;
-constexpr uint32_t kJuliaStaticLdsBytes = 46 * 1024;     // upper bound of its static LDS (job table + rings)
+constexpr uint32_t kJuliaStaticLdsBytes = 50 * 1024;     // upper bound of its static LDS (job table + rings)
 
 enum CounterSlot : int {
     C_PRIMARY = 0, C_SECONDARY, C_SHADOW, C_PHOTON_SEGMENTS, C_PHOTON_DEPOSITS, C_SPHERE_TESTS, C_TRIANGLE_TESTS,
