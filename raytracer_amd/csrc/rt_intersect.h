@@ -219,23 +219,23 @@ RT_DEV float julia_distance_tail(float m2, float d2) {
     return static_cast<float>(tail);
 }
 
-// The same value by a shorter route, for the march loop (one tail per march step).  E = sqrt(q) *
-// 0.25 * ln(m2) is evaluated in double with a relative error below 2^-51 (float-seeded Newton
-// square root and reciprocal, atanh series for the logarithm; error measured against 80-bit
-// arithmetic on 10^8 operands by the model in tools/fast_tail_model.c), the reference's own double
-// expression is within 2^-50 of the same real number, so both round to the same float unless E lies
-// within 2^-44*E of a rounding boundary.  That case, and every operand outside the plain range
-// (m2 < 4, infinities, NaNs, zero or denormal results), returns false and the caller evaluates the
-// reference's expression itself (julia_distance_tail).
+// The same value by a shorter route (one tail per march step and six per normal estimate).
+// E = sqrt(q) * 0.5 * ln(S), S = sqrt((double)m2) correctly rounded exactly as the reference forms it,
+// is evaluated in double with a relative error below 2^-50 (float-seeded Newton square root and
+// reciprocal, atanh series for the logarithm of S; error measured against 80-bit arithmetic on 10^8
+// operands by the model in tools/fast_tail_model.c).  The reference's own double expression (glibc
+// log within an ulp, two products) is within 2^-50 of the same real number, so both round to the
+// same float unless E lies within 2^-44*E of a rounding boundary.  That case, and every operand
+// outside the plain range (infinities, NaNs, zeros, denormal results), returns false and the caller
+// evaluates the reference's expression itself (julia_distance_tail).
 RT_DEV bool julia_distance_tail_fast(float m2, float d2, float& out) {
     if (d2 == __builtin_inff() && m2 > 0.0f && m2 < __builtin_inff()) {
-        // interior point: sqrt(m2/inf) = 0 times a finite logarithm; the sign of the zero is never looked
-        // at (julia_advance only compares it with the thresholds)
-        out = 0.0f;
+        // interior point: sqrt(m2/inf) = +0 times a finite logarithm, a zero with the logarithm's sign
+        out = m2 < 1.0f ? -0.0f : 0.0f;
         return true;
     }
     const float q = m2 / d2;
-    if (!(m2 >= 4.0f && m2 < __builtin_inff() && q >= 1e-30f && q < 1e30f)) return false;
+    if (!(m2 >= 1e-30f && m2 < __builtin_inff() && q >= 1e-30f && q < 1e30f)) return false;
     const double x = static_cast<double>(q);
     double g, h;
     {
@@ -252,7 +252,7 @@ RT_DEV bool julia_distance_tail_fast(float m2, float d2, float& out) {
         g = __builtin_fma(d, h, g);   // sqrt(q)
     }
     int e;
-    double m = __builtin_frexp(static_cast<double>(m2), &e);   // [0.5, 1)
+    double m = __builtin_frexp(__builtin_sqrt(static_cast<double>(m2)), &e);   // [0.5, 1)
     if (m < 0.70710678118654752) {
         m *= 2.0;
         e -= 1;
@@ -277,7 +277,7 @@ RT_DEV bool julia_distance_tail_fast(float m2, float d2, float& out) {
     p = p * s2;
     const double lnm = 2.0 * __builtin_fma(s, p, s);
     const double ln = __builtin_fma(static_cast<double>(e), 0.69314718055994530942, lnm);
-    const double big = g * 0.25 * ln;
+    const double big = g * 0.5 * ln;
     const float f = static_cast<float>(big);
     const unsigned bits = __float_as_uint(f);
     const unsigned ex = bits & 0x7f800000u;
@@ -302,7 +302,7 @@ RT_DEV float julia_distance(Quat z, Quat c, unsigned iterations, unsigned long l
         if (COUNT) n_iter++;
         if (julia_pk_iterate(s, cp, cq)) break;
     }
-    return julia_distance_tail(s.m2, s.d2);
+    return julia_distance_tail_auto(s.m2, s.d2);
 }
 
 // Julia::estimateNormal (src/objects.cpp:140-160), object space

@@ -28,6 +28,9 @@ namespace rtd {
 #ifndef RT_TRACE_WAVES_PER_SIMD
 #define RT_TRACE_WAVES_PER_SIMD 3   // measured on C2/C3: 3 beats 2 (occupancy) and 4 (spills)
 #endif
+#ifndef RT_PHOTON_WAVES_PER_SIMD
+#define RT_PHOTON_WAVES_PER_SIMD 3
+#endif
 #ifndef RT_TRI_GROUP
 #define RT_TRI_GROUP 4
 #endif
@@ -1219,7 +1222,7 @@ __global__ __launch_bounds__(256) void sum_samples_kernel(const float4* __restri
 // a stack of pending rays; deposits are float atomics into the photon atlas (their order is not the
 // reference's sequential one: texels agree to rounding, not bit for bit).
 template <bool HAS_JULIA, bool STATS>
-__global__ __launch_bounds__(256) void photon_kernel(const DevScene sc, const DevPhotonJob job) {
+__global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(const DevScene sc, const DevPhotonJob job) {
     Counters n;
     if (STATS) for (int i = 0; i < C_COUNT; i++) n.v[i] = 0;
     const unsigned long long grid_lanes = static_cast<unsigned long long>(gridDim.x) * blockDim.x;

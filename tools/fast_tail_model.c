@@ -14,7 +14,8 @@ static int n_fallback=0;
 static double g_maxrel=0; static long g_nfast=0;
 static int fast(float m2,float d2,float*out,int perturb){
   float q=m2/d2;
-  if(!(m2>=4.0f && m2<INFINITY && q>=1e-30f && q<1e30f)) return 0;
+  if(d2==INFINITY && m2>0.0f && m2<INFINITY){ *out=m2<1.0f?-0.0f:0.0f; return 1; }
+  if(!(m2>=1e-30f && m2<INFINITY && q>=1e-30f && q<1e30f)) return 0;
   // sqrt(q) in double: rsq seed in float
   float y0f=1.0f/sqrtf(q); 
   if(perturb){ uint32_t u=asu(y0f); u+= (int)(rnd()%9)-4; y0f=asf(u);} // +-4ulp
@@ -27,7 +28,7 @@ static int fast(float m2,float d2,float*out,int perturb){
   double d=fma(-g,g,x);
   g=fma(d,h,g);            // sqrt(q), ~0.5ulp
   // ln(m2)
-  double xm=(double)m2;
+  double xm=sqrt((double)m2);   // correctly rounded, as the reference forms it
   int e; double m=frexp(xm,&e); // m in [0.5,1)
   if(m<0.70710678118654752){ m*=2.0; e-=1; }  // m in [0.707,1.414)
   double num=m-1.0, den=m+1.0;
@@ -43,8 +44,8 @@ static int fast(float m2,float d2,float*out,int perturb){
   p=p*s2; // series minus leading 1
   double lnm=2.0*fma(sN,p,sN);
   double ln=fma((double)e,0.69314718055994530942,lnm);
-  double E=g*0.25*ln;   // sqrt(q)*0.5 * (0.5*ln(m2))
-  { long double T=sqrtl((long double)q)*0.25L*logl((long double)m2); double rel=fabs((double)((E-T)/T)); if(rel>g_maxrel) g_maxrel=rel; }
+  double E=g*0.5*ln;   // sqrt(q)*0.5 * (0.5*ln(m2))
+  { long double T=sqrtl((long double)q)*0.5L*logl((long double)sqrt((double)m2)); double rel=fabs((double)((E-T)/T)); if(rel>g_maxrel) g_maxrel=rel; }
   float f=(float)E;
   uint32_t fb=asu(f);
   uint32_t ex=fb&0x7f800000u;
@@ -60,7 +61,8 @@ int main(int argc,char**argv){
     // m2: mix of escaped values (1e10..1e20), moderate, and arbitrary
     uint64_t r=rnd(); float m2,d2;
     int mode=(argc>2)?0:(r&7);
-    if(mode<5){ m2=1e10f*expf((float)((rnd()>>11)*(1.0/9007199254740992.0))*23.0f); }
+    if(argc>2 && argv[2][0]=='n'){ m2=expf((float)((rnd()>>11)*(1.0/9007199254740992.0))*6.0f-3.0f); }
+    else if(mode<5){ m2=1e10f*expf((float)((rnd()>>11)*(1.0/9007199254740992.0))*23.0f); }
     else if(mode<7){ m2=expf((float)((rnd()>>11)*(1.0/9007199254740992.0))*40.0f-5.0f); }
     else { m2=asf((uint32_t)rnd()&0x7fffffffu); }
     // randomise mantissa fully
