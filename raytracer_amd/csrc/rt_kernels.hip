@@ -6,9 +6,8 @@
 //   PhotonMapper::generate / castRay                 src/photonmap.cpp:20-146
 //
 // Execution model (not a translation of the reference's recursion):
-//   * one lane = one primary sample (pixel, sub-pixel, hue) at a time; lanes pull samples from a
-//     global queue in 8x8-pixel tiles, so a wave starts coherent and is refilled as lanes finish
-//     (persistent waves: divergence is cut by refill instead of by leaving lanes idle);
+//   * one lane = one primary sample (pixel, sub-pixel, hue) at a time; persistent waves pull 8x8-pixel
+//     tiles from a global queue; a wave finishes its tile before it takes the next (RT_REFILL_MIN);
 //   * the recursion is a per-lane post-order DFS with an explicit frame stack in HBM
 //     ([frame][field][lane], coalesced), so child radiance is combined in the reference's order;
 //   * the expensive operation — one ray against every scene object — is a single wave-uniform
@@ -30,6 +29,14 @@ namespace rtd {
 #endif
 #ifndef RT_PHOTON_WAVES_PER_SIMD
 #define RT_PHOTON_WAVES_PER_SIMD 3
+#endif
+// idle lanes a wave collects before it takes new samples.  64 = a wave takes a whole 8x8 tile, finishes
+// it and only then takes the next one: measured against refilling every lane as soon as it is idle
+// (1), C2 2.58 -> 2.12 ms and C3 19.3 -> 12.1 ms — lanes that start together stay in the same kind of
+// phase (trace, shadow 0, shadow 1 ...), so a resolve phase runs one branch instead of all of them,
+// which is worth more than the idle lanes cost
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 64
 #endif
 #ifndef RT_TRI_GROUP
 #define RT_TRI_GROUP 4
@@ -720,6 +727,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
     L.jidx = 0;
     L.jstep = 0;
     bool fresh = true;         // lane holds no sample yet
+    bool want = false;         // lane is idle and waits for the next refill
     WaveIds wave_ids = {0ull, 0ull};
 
     for (;;) {
@@ -747,9 +755,15 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
             if (mine && !fresh) resolve_lane<STATS>(sc, T, job, stack, L, n, done, value);
             t_fetch_outer = STATS ? clock64() : 0;
             if (mine && done) store_sample(sc, job, L, value);
-            bool need = mine && (fresh || done);
-            if (need) L.state = S_IDLE;
-            // refill from the queue; padding lanes of edge tiles simply ask again
+            if (mine && (fresh || done)) {
+                L.state = S_IDLE;
+                want = true;
+            }
+            // refill from the queue once RT_REFILL_MIN lanes are idle, or when nothing else is left to do;
+            // padding lanes of edge tiles simply ask again
+            const int n_want = __popcll(__ballot(want)), n_live = __popcll(__ballot(L.state == S_QUERY));
+            bool need = want && (n_want >= RT_REFILL_MIN || n_live == 0);
+            if (need) want = false;
             while (__any(need)) {
                 unsigned long long id = 0;
                 const bool got = fetch_ids(job.queue_head, job.n_samples, job.id_chunk, wave_ids, need, id);
@@ -792,6 +806,9 @@ static_assert(sizeof(float) * (11 + 11) * kJuliaTracerLanes + 16 * kJuliaQueueCa
 static_assert(kJuliaQueueCap >= kJuliaTracerLanes && (kJuliaQueueCap & (kJuliaQueueCap - 1)) == 0, "ring size");
 #ifndef RT_JULIA_STEP_DIVISOR
 #define RT_JULIA_STEP_DIVISOR 2
+#endif
+#ifndef RT_JULIA_REFILL_MIN
+#define RT_JULIA_REFILL_MIN 1
 #endif
 #ifndef RT_JULIA_TRACER_MIN_READY
 #define RT_JULIA_TRACER_MIN_READY 12        // a tracer wave waits for this many serviceable lanes while the marchers have work
@@ -1070,6 +1087,7 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
     L.jidx = 0;
     L.jstep = 0;
     bool fresh = true;
+    bool want = false;
     WaveIds wave_ids = {0ull, 0ull};
     unsigned wait_rounds = 0;
     long long t_mark = STATS ? clock64() : 0;
@@ -1155,8 +1173,14 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
             Col value = {0.0f, 0.0f, 0.0f, 0.0f};
             if (mine && !fresh) resolve_lane<STATS>(sc, T, job, stack, L, n, done, value);
             if (mine && done) store_sample(sc, job, L, value);
-            bool need = mine && (fresh || done);
-            if (need) L.state = S_IDLE;
+            if (mine && (fresh || done)) {
+                L.state = S_IDLE;
+                want = true;
+            }
+            const int n_want = __popcll(__ballot(want));
+            const int n_live = __popcll(__ballot(L.state == S_QUERY || L.state == S_WAIT));
+            bool need = want && (n_want >= RT_JULIA_REFILL_MIN || n_live == 0);
+            if (need) want = false;
             while (__any(need)) {
                 unsigned long long id = 0;
                 const bool got = fetch_ids(job.queue_head, job.n_samples, job.id_chunk, wave_ids, need, id);
