@@ -32,7 +32,7 @@ __global__ void quantize_kernel(const float4* rgba, uchar4* out, float gain, uns
 hipError_t build_triangle_bvh(const DevTriTest* tris, uint32_t first, uint32_t n, DevBvhNode* nodes);
 constexpr int kFrameFieldsHost = 11;
 constexpr size_t kMaxLdsBlobBytes = 28 * 1024;   // + 11 KB of frame tops: keeps 4 blocks per CU within the 160 KB LDS
-constexpr size_t kMaxLdsBlobBytesJulia = 64 * 1024 - kJuliaStaticLdsBytes;   // trace_julia_kernel: blob + its queues stay under 64 KB
+constexpr size_t kMaxLdsBlobBytesJulia = 24 * 1024;   // trace_julia_kernel: one workgroup per CU, 68 KB of its own LDS   // trace_julia_kernel: blob + its queues stay under 64 KB
 constexpr int kJuliaBlockThreads = kJuliaWaves * 64, kJuliaTracerLanesHost = (kJuliaWaves - kJuliaMarcherWaves) * 64;
 }  // namespace rtd
 
@@ -185,6 +185,11 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
         if (stats) RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_julia_kernel<true>, kJuliaBlockThreads, lds));
         else RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_julia_kernel<false>, kJuliaBlockThreads, lds));
         if (per_cu < 1) return fail(ctx, RT_ERR_HIP, "trace_julia_kernel does not fit a compute unit");
+        if (lds > 0) {
+            // static + dynamic LDS exceeds 64 KB: opt in (gfx950 has 160 KB per CU)
+            if (stats) RT_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_julia_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            else RT_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_julia_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        }
         const uint64_t needed = (job.n_samples + kJuliaTracerLanesHost - 1) / kJuliaTracerLanesHost;
         blocks = static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(ctx->n_cus), needed ? needed : 1));
         lanes = static_cast<uint64_t>(blocks) * kJuliaTracerLanesHost;

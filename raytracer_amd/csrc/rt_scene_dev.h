@@ -179,14 +179,17 @@ struct DevPhotonJob {
 
 // Shape of trace_julia_kernel's workgroup (rt_kernels.hip), shared with the launch code
 #ifndef RT_JULIA_WAVES
-#define RT_JULIA_WAVES 12
+#define RT_JULIA_WAVES 16
 #endif
 #ifndef RT_JULIA_MARCHERS
-#define RT_JULIA_MARCHERS 5
+#define RT_JULIA_MARCHERS 7
 #endif
 constexpr int kJuliaWaves = RT_JULIA_WAVES;              // per workgroup, a multiple of 4 (waves per SIMD = kJuliaWaves / 4)
 constexpr int kJuliaMarcherWaves = RT_JULIA_MARCHERS;
-constexpr uint32_t kJuliaStaticLdsBytes = 50 * 1024;     // upper bound of its static LDS (job table + rings)
+#ifndef RT_JULIA_STATIC_LDS_KB
+#define RT_JULIA_STATIC_LDS_KB 68
+#endif
+constexpr uint32_t kJuliaStaticLdsBytes = RT_JULIA_STATIC_LDS_KB * 1024;     // upper bound of its static LDS (job table + rings)
 
 enum CounterSlot : int {
     C_PRIMARY = 0, C_SECONDARY, C_SHADOW, C_PHOTON_SEGMENTS, C_PHOTON_DEPOSITS, C_SPHERE_TESTS, C_TRIANGLE_TESTS,
