@@ -265,7 +265,7 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream) {
         job.id_chunk = id_chunk_for(job.n_roots, lanes);
         job.queue_head = ctx->d_queue;
         job.counters = ctx->d_counters;
-        RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), stream));
+        RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 2 * sizeof(unsigned long long), stream));
         if (julia) {
             if (stats) hipLaunchKernelGGL((photon_kernel<true, true>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
             else hipLaunchKernelGGL((photon_kernel<true, false>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
@@ -359,6 +359,7 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
         return fail(nullptr, RT_ERR_HIP, "cannot allocate context resources on device %d", device_id);
     }
     (void)hipMemset(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long));
+    (void)hipMemset(ctx->d_queue, 0, 256);   // [0] queue head, [1] watchdog flag of trace_julia_kernel
     *out_ctx = ctx;
     return RT_OK;
 }
