@@ -158,6 +158,9 @@ struct DevJob {
     unsigned long long* counters;// rt_stats words (only touched when STATS)
     uint32_t dof_seed;
     uint32_t id_chunk;           // sample ids a wave reserves per atomic (multiple of 64)
+    uint32_t static_blocks;      // 64-id blocks every wave owns outright: wave w of n_waves owns blocks w, w + n_waves, ...
+    uint32_t n_waves;
+    uint64_t dyn_base;           // first id handed out through queue_head
 };
 
 // Photon emission job (src/photonmap.cpp:38-57)
@@ -175,6 +178,9 @@ struct DevPhotonJob {
     unsigned long long* queue_head;
     unsigned long long* counters;
     uint32_t id_chunk;              // root ids a wave reserves per atomic
+    uint32_t static_blocks;         // as in DevJob
+    uint32_t n_waves;
+    uint64_t dyn_base;
 };
 
 // Shape of trace_julia_kernel's workgroup (rt_kernels.hip), shared with the launch code
