@@ -1261,38 +1261,6 @@ __global__ __launch_bounds__(256) void sum_samples_kernel(const float4* __restri
     out[p] = make_float4(px.r, px.g, px.b, px.a);
 }
 
-// ---- pending rays of the photon pass, shared by the lanes of a workgroup ------------------------------
-// A root that enters a refractive object grows a binary tree of up to 2^(max_bounces+1) segments; walked
-// by one lane that is a serial chain of ~1.5 us steps and was the critical path of the whole pass
-// (C5: 1.1 ms for work worth 0.4 ms).  The reflection branch of every split therefore goes on a ring in
-// LDS from which ANY idle lane of the workgroup takes it; a lane's private HBM stack only catches the
-// overflow.  Same ticket + sequence-word protocol as JuliaRing.
-constexpr unsigned kPhotonRingCap = 512;
-enum PhotonField : int { PF_OX = 0, PF_OY, PF_OZ, PF_DX, PF_DY, PF_DZ, PF_R, PF_G, PF_B, PF_A, PF_DEPTH, PF_WAVELENGTH, PF_COUNT };
-struct PhotonRing {
-    unsigned head, tail, pad0, pad1;
-    unsigned ready[kPhotonRingCap];          // == i+1 while entry i is written and not yet read
-    float rec[PF_COUNT][kPhotonRingCap];
-};
-// Reserves `cnt` entries for writing if the ring has room for all of them.
-RT_DEV bool photon_ring_reserve(PhotonRing& q, unsigned cnt, unsigned& first) {
-    unsigned ok = 0, t = 0;
-    if ((threadIdx.x & 63) == 0) {
-        for (int attempt = 0; attempt < 16; attempt++) {
-            t = lds_load(&q.tail);
-            const unsigned h = lds_load(&q.head);
-            if (t - h + cnt > kPhotonRingCap) break;
-            unsigned expect = t;
-            if (__hip_atomic_compare_exchange_strong(&q.tail, &expect, t + cnt, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                ok = 1;
-                break;
-            }
-        }
-    }
-    first = __shfl(t, 0);
-    return __shfl(ok, 0) != 0u;
-}
-
 // ---- photon pass (src/photonmap.cpp:20-146) ---------------------------------------------------------
 // One lane = one root direction (light, phi, theta, hue).  The path tree is walked depth first with
 // a stack of pending rays; deposits are float atomics into the photon atlas (their order is not the
@@ -1316,11 +1284,6 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
         table_base = lds_blob;
     }
     const ShadeTables T = tables_of(sc, table_base);
-    __shared__ PhotonRing ring;
-    for (unsigned i = threadIdx.x; i < kPhotonRingCap; i += blockDim.x) ring.ready[i] = 0u;
-    if (threadIdx.x == 0) ring.head = ring.tail = 0u;
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
     Lane L;
     L.state = S_IDLE;
     L.sp = 0;
@@ -1329,36 +1292,7 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
     bool need = true;
     WaveIds wave_ids = wave_ids_begin(gid, job.n_waves, job.static_blocks);
     for (;;) {
-        // idle lanes first take pending rays that any lane of the workgroup has shared
-        need = L.state != S_QUERY;
-        {
-            const unsigned long long idle = __ballot(need);
-            if (idle != 0ull && lds_load(&ring.tail) != lds_load(&ring.head)) {
-                unsigned first = 0;
-                const unsigned got = ring_pop(&ring.head, &ring.tail, static_cast<unsigned>(__popcll(idle)), first);
-                const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
-                if (need && rank < got) {
-                    const unsigned i = first + rank, slot = i & (kPhotonRingCap - 1);
-                    unsigned spins = 0;
-                    while (lds_load(&ring.ready[slot]) != i + 1u && ++spins < kSpinLimit) {}
-                    lds_acquire();
-                    const V3 o = v3(lds_loadf(&ring.rec[PF_OX][slot]), lds_loadf(&ring.rec[PF_OY][slot]), lds_loadf(&ring.rec[PF_OZ][slot]));
-                    const V3 d = v3(lds_loadf(&ring.rec[PF_DX][slot]), lds_loadf(&ring.rec[PF_DY][slot]), lds_loadf(&ring.rec[PF_DZ][slot]));
-                    rad[0] = lds_loadf(&ring.rec[PF_R][slot]);
-                    rad[1] = lds_loadf(&ring.rec[PF_G][slot]);
-                    rad[2] = lds_loadf(&ring.rec[PF_B][slot]);
-                    rad[3] = lds_loadf(&ring.rec[PF_A][slot]);
-                    depth = __float_as_uint(lds_loadf(&ring.rec[PF_DEPTH][slot]));
-                    L.wavelength = lds_loadf(&ring.rec[PF_WAVELENGTH][slot]);
-                    lds_release();
-                    lds_store(&ring.ready[slot], 0u);   // the slot may be written again
-                    L.sp = 0;
-                    need = false;
-                    begin_query(L, o, d, kInfinite, Q_PHOTON);
-                }
-            }
-        }
-        // the others take new roots
+        // refill idle lanes with new roots
         while (__any(need)) {
             unsigned long long id = 0;
             const bool got = fetch_ids(job.queue_head, job.dyn_base, job.n_roots, job.id_chunk, wave_ids, need, id);
@@ -1388,15 +1322,9 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                 }
             }
         }
-        if (!__any(L.state == S_QUERY)) {
-            if (lds_load(&ring.tail) == lds_load(&ring.head)) break;
-            continue;   // roots are exhausted for this wave; shared rays are not
-        }
+        if (!__any(L.state == S_QUERY)) break;
 
         const bool mine = L.state == S_QUERY;
-        bool share = false;                 // this lane has a reflection branch to hand over
-        V3 share_o = {0, 0, 0}, share_d = {0, 0, 0};
-        float share_rad[4] = {0, 0, 0, 0};
         query_objects<STATS>(sc, L, mine, n);
         if (mine) {
             bump<STATS>(n, C_PHOTON_SEGMENTS);
@@ -1435,11 +1363,13 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                     const bool refr_ok = kr < 1.0f && refraction_ray(L.qd, L.best.point, L.best.normal, m.refr_re, m.dispersion, cosv, L.wavelength, ro, rd);
                     reflection_ray(L.qd, L.best.point, L.best.normal, cosv, mo, md);
                     if (refr_ok) {
-                        // reflection (always cast, src/photonmap.cpp:141-144) is handed over below
-                        share = true;
-                        share_o = mo;
-                        share_d = md;
-                        for (int c = 0; c < 4; c++) share_rad[c] = rad[c] * kr;
+                        // reflection (always cast, src/photonmap.cpp:141-144) waits on the stack
+                        const unsigned f = L.sp;
+                        stack.at(f, 0) = mo.x; stack.at(f, 1) = mo.y; stack.at(f, 2) = mo.z;
+                        stack.at(f, 3) = md.x; stack.at(f, 4) = md.y; stack.at(f, 5) = md.z;
+                        for (int c = 0; c < 4; c++) stack.at(f, 6 + c) = rad[c] * kr;
+                        stack.at(f, 10) = __uint_as_float(depth + 1);
+                        L.sp = f + 1;
                         for (int c = 0; c < 4; c++) rad[c] = rad[c] * (1 - kr);
                         begin_query(L, ro, rd, kInfinite, Q_PHOTON);
                     } else {
@@ -1462,43 +1392,6 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                 } else {
                     L.state = S_IDLE;
                     need = true;
-                }
-            }
-        }
-        // hand the reflection branches to the workgroup (all of the wave's or, when the ring is full,
-        // none: those go on the lane's own stack in HBM).  `depth` was already advanced for the child.
-        {
-            const unsigned long long sharers = __ballot(share);
-            if (sharers != 0ull) {
-                unsigned first = 0;
-                const bool room = photon_ring_reserve(ring, static_cast<unsigned>(__popcll(sharers)), first);
-                if (share) {
-                    if (room) {
-                        const unsigned i = first + __popcll(sharers & ((1ull << lane) - 1ull)), slot = i & (kPhotonRingCap - 1);
-                        unsigned spins = 0;
-                        while (lds_load(&ring.ready[slot]) != 0u && ++spins < kSpinLimit) {}   // its previous reader
-                        lds_storef(&ring.rec[PF_OX][slot], share_o.x);
-                        lds_storef(&ring.rec[PF_OY][slot], share_o.y);
-                        lds_storef(&ring.rec[PF_OZ][slot], share_o.z);
-                        lds_storef(&ring.rec[PF_DX][slot], share_d.x);
-                        lds_storef(&ring.rec[PF_DY][slot], share_d.y);
-                        lds_storef(&ring.rec[PF_DZ][slot], share_d.z);
-                        lds_storef(&ring.rec[PF_R][slot], share_rad[0]);
-                        lds_storef(&ring.rec[PF_G][slot], share_rad[1]);
-                        lds_storef(&ring.rec[PF_B][slot], share_rad[2]);
-                        lds_storef(&ring.rec[PF_A][slot], share_rad[3]);
-                        lds_storef(&ring.rec[PF_DEPTH][slot], __uint_as_float(depth));
-                        lds_storef(&ring.rec[PF_WAVELENGTH][slot], L.wavelength);
-                        lds_release();
-                        lds_store(&ring.ready[slot], i + 1u);
-                    } else {
-                        const unsigned f = L.sp;
-                        stack.at(f, 0) = share_o.x; stack.at(f, 1) = share_o.y; stack.at(f, 2) = share_o.z;
-                        stack.at(f, 3) = share_d.x; stack.at(f, 4) = share_d.y; stack.at(f, 5) = share_d.z;
-                        for (int c = 0; c < 4; c++) stack.at(f, 6 + c) = share_rad[c];
-                        stack.at(f, 10) = __uint_as_float(depth);
-                        L.sp = f + 1;
-                    }
                 }
             }
         }
