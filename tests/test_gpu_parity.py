@@ -446,3 +446,49 @@ def test_two_julia_sets_through_the_job_queues(tmp_path):
     img2, _ = ctx.render()
     assert np.array_equal(img.view(np.uint32), img2.view(np.uint32))
     ctx.close()
+
+
+# ---- every example scene the reference ships -----------------------------------------------------------
+
+ALL_SCENES = [
+    ("examples/example2.xml", 0.0), ("examples/example3.xml", 0.0), ("examples/example4.xml", 0.0),
+    ("examples/example5.xml", 0.0), ("examples/example6.xml", 0.0), ("examples/example7.xml", 0.0),
+    ("examples/example8.xml", 0.0), ("examples/example9.xml", 0.0),
+    ("examples2/2_animation.xml", 0.37), ("examples2/3_motionblur.xml", 0.61), ("examples2/5_julia_animation.xml", 0.25),
+    ("examples2/9_caustic.xml", 0.0), ("examples2/10_caustic_texture.xml", 0.0),
+    ("examples3/102_fresnel_animation.xml", 0.8), ("examples3/104_julia_animation.xml", 0.5),
+]
+
+
+@pytest.mark.parametrize("rel,t", ALL_SCENES)
+def test_every_example_scene_vs_oracle(hip_ctx, rel, t):
+    """The remaining example scenes of the reference (the oracle is pinned to the reference itself on
+    each of them by tests/test_oracle_golden.py::test_oracle_vs_live_reference).  Float pictures are
+    bit-exact; with a photon map they agree to the rounding of the deposit order."""
+    sc = capi.Scene(scene_path(rel), t)
+    if sc.width * sc.height > 600 * 600:
+        sc.set_camera(512, 512, 0)          # example9.xml is 2048x2048; its 4K variant is tested at full size
+    hip_ctx.upload(sc)
+    hip_ctx.set_option(capi.RT_OPT_COLLECT_STATS, 0)
+    hip_ctx.photon_generate()
+    img, _ = hip_ctx.render()
+    ph = oracle_lib.Photons(sc) if sc.desc.photon_steps > 0 else None
+    ref, _ = oracle_lib.render(sc, ph, threads=16)
+    # a TEXTURED sphere takes its texture coordinates from atan2f/asinf (src/objects.cpp:47): the device
+    # functions are within 2 ulp of glibc's, not identical (documented deviation, DESIGN.md section 2)
+    d = sc.desc
+    textured_sphere = any(d.objects[i].kind == capi.RT_OBJ_SPHERE and d.materials[d.objects[i].material].texture >= 0
+                          for i in range(d.n_objects))
+    if ph is None and not textured_sphere:
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), rel
+    elif textured_sphere:
+        # a 2-ulp shift of uv moves a few samples across a texel boundary: the bar is the north star's
+        # (at most 1 LSB on 99.9 % of the pixels, PSNR >= 50 dB), and nearly all floats are within 1e-5
+        dd = assert_north_star(capi.quantize(img), capi.quantize(ref), rel)
+        close = np.isclose(img, ref, rtol=1e-5, atol=1e-7).all(axis=2)
+        print(rel, dd, "pixels beyond 1e-5:", int((~close).sum()))
+        assert (~close).mean() < 1e-3
+    else:
+        assert np.allclose(img, ref, rtol=1e-5, atol=1e-7), rel
+        dd = assert_north_star(capi.quantize(img), capi.quantize(ref), rel)
+        assert dd["max"] <= 1

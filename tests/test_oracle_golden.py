@@ -99,12 +99,28 @@ def test_kat_records_bit_exact():
             assert kr.view(np.uint32) == r[3], (name, f[1], f[2])
 
 
+LIVE = [
+    ("examples2/1_transparent.xml", 0.0),
+    # every other example scene the reference ships (scenes/ holds copies of the data files)
+    ("examples/example2.xml", 0.0), ("examples/example3.xml", 0.0), ("examples/example4.xml", 0.0),
+    ("examples/example5.xml", 0.0), ("examples/example6.xml", 0.0), ("examples/example7.xml", 0.0),
+    ("examples/example8.xml", 0.0),
+    ("examples2/2_animation.xml", 0.37), ("examples2/3_motionblur.xml", 0.61), ("examples2/5_julia_animation.xml", 0.25),
+    ("examples3/102_fresnel_animation.xml", 0.8), ("examples3/104_julia_animation.xml", 0.5),
+]
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(oracle_lib.REF_DIR, "ref_harness")), reason="reference build absent (GPU box)")
-def test_oracle_vs_live_reference(tmp_path):
-    scene = scene_path("examples2/1_transparent.xml")
+@pytest.mark.parametrize("rel,t", LIVE)
+def test_oracle_vs_live_reference(tmp_path, rel, t):
+    """The reference itself (oracle/_ref/ref_harness = our harness linked against the reference's
+    objects) renders the scene at time t; the oracle's float picture must equal it bit for bit."""
+    scene = scene_path(rel)
     out = str(tmp_path / "ref.f32")
-    subprocess.check_call([os.path.join(oracle_lib.REF_DIR, "ref_harness"), "render", scene, "0", out])
+    subprocess.check_call([os.path.join(oracle_lib.REF_DIR, "ref_harness"), "render", scene, repr(t), out])
     raw = np.fromfile(out, dtype=np.uint32)
     ref = raw[2:].view(np.float32).reshape(int(raw[1]), int(raw[0]), 4)
-    img, _ = oracle_lib.render(capi.Scene(scene, 0.0), None, threads=8)
+    sc = capi.Scene(scene, t)
+    photons = oracle_lib.Photons(sc) if sc.desc.photon_steps > 0 else None
+    img, _ = oracle_lib.render(sc, photons, threads=8)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
