@@ -3,6 +3,7 @@
 #pragma once
 
 #include "rt_device_math.h"
+#include "rt_libm.h"
 #include "rt_scene_dev.h"
 
 namespace rtd {
@@ -122,7 +123,7 @@ RT_DEV bool sphere_intersect(P s, V3 o_w, V3 d_w, float maxd, HitRec& h) {
     }
     const V3 p = o + d * t;
     const V3 n = normalized(p - center);
-    const V2 uv = {0.5f + atan2f(n.x, n.z) / (2.0f * kPi), 0.5f - asinf(n.y) / kPi};
+    const V2 uv = {0.5f + glibc_atan2f(n.x, n.z) / (2.0f * kPi), 0.5f - glibc_asinf(n.y) / kPi};   // rt_libm.h: glibc's own sequences
     const V3 pw = xform_point(s->o2w, p);
     h.dist = length(o_w - pw);
     h.point = pw;

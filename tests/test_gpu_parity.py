@@ -62,16 +62,9 @@ def test_intersectors_against_reference_answers(hip_ctx, name, rel):
     kinds = np.array([sc.desc.objects[int(o)].kind for o in objs])
     got = out[hit][:, 1:12].view(np.uint32)
     want = recs[hit][:, 9:20]
-    # triangles and Julia sets: bit-exact.  Spheres: uv goes through atan2f/asinf, whose device
-    # versions are not glibc's — 2 ulp allowed on those two words only.
-    tri_or_julia = kinds[hit] != capi.RT_OBJ_SPHERE
-    assert np.array_equal(got[tri_or_julia], want[tri_or_julia])
-    sph = ~tri_or_julia
-    if sph.any():
-        assert np.array_equal(got[sph][:, :7], want[sph][:, :7])
-        a = got[sph][:, 7:].view(np.float32)
-        b = want[sph][:, 7:].view(np.float32)
-        assert np.all(np.abs(a - b) <= 3e-7)
+    # every kind bit-exact, the sphere's uv included: asinf/atan2f are glibc's own operation sequences
+    # on the device (raytracer_amd/csrc/rt_libm.h, pinned exhaustively by tests/test_libm_model.py)
+    assert np.array_equal(got, want), (kinds[hit][np.any(got != want, axis=1)][:8])
     if len(fres):
         rec5 = np.zeros((len(fres), 5), dtype=np.float32)
         for i, r in enumerate(fres):
@@ -474,20 +467,10 @@ def test_every_example_scene_vs_oracle(hip_ctx, rel, t):
     img, _ = hip_ctx.render()
     ph = oracle_lib.Photons(sc) if sc.desc.photon_steps > 0 else None
     ref, _ = oracle_lib.render(sc, ph, threads=16)
-    # a TEXTURED sphere takes its texture coordinates from atan2f/asinf (src/objects.cpp:47): the device
-    # functions are within 2 ulp of glibc's, not identical (documented deviation)
-    d = sc.desc
-    textured_sphere = any(d.objects[i].kind == capi.RT_OBJ_SPHERE and d.materials[d.objects[i].material].texture >= 0
-                          for i in range(d.n_objects))
-    if ph is None and not textured_sphere:
+    # textured spheres included: their texture coordinates go through rt_libm.h's restatement of glibc's
+    # atan2f/asinf (src/objects.cpp:47), so example8 is bit-exact like the rest
+    if ph is None:
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), rel
-    elif textured_sphere:
-        # a 2-ulp shift of uv moves a few samples across a texel boundary: the bar is the north star's
-        # (at most 1 LSB on 99.9 % of the pixels, PSNR >= 50 dB), and nearly all floats are within 1e-5
-        dd = assert_north_star(capi.quantize(img), capi.quantize(ref), rel)
-        close = np.isclose(img, ref, rtol=1e-5, atol=1e-7).all(axis=2)
-        print(rel, dd, "pixels beyond 1e-5:", int((~close).sum()))
-        assert (~close).mean() < 1e-3
     else:
         assert np.allclose(img, ref, rtol=1e-5, atol=1e-7), rel
         dd = assert_north_star(capi.quantize(img), capi.quantize(ref), rel)
