@@ -9,6 +9,9 @@ Needs oracle/_ref/ (built by `make -C oracle` from /root/reference/src, "O-stric
   <name>.fp.bin        flattened-scene word stream (ref_harness fingerprint) for the loader test
   <name>.kat.bin       Object::intersect / calcFresnel known answers (ref_harness kat)
   <name>.photon.bin    sparse photon textures after PhotonMapper::generate (ref_harness render)
+  ofast/<name>.png     the same scenes from the reference built with its own Makefile flags
+                       (-Ofast -flto -march=native; host-dependent, the SECONDARY parity target of
+                       SURVEY 8c): `make_golden.py ofast`
 """
 import json
 import os
@@ -23,6 +26,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = os.path.join(ROOT, "oracle", "_ref")
 HARNESS = os.path.join(REF, "ref_harness")
 REF_EXE = os.path.join(REF, "raytracer_ostrict")
+REF_EXE_FAST = os.path.join(REF, "raytracer_ofast")
+OFAST_CONFIGS = ["c1_example1", "c2_example9_lowres", "c3_fresnel", "c4_julia_shiny", "c5_caustic_animation"]
 SCENES = os.path.join(ROOT, "scenes")
 
 # name -> (scene file, times for float rows, number of float rows kept)
@@ -94,8 +99,18 @@ def main():
         out = os.path.join(HERE, name + ".png")
         timings[name + ".png"] = run([REF_EXE, os.path.join(SCENES, rel), out])
         print(name, "png done %.1fs" % timings[name + ".png"], flush=True)
+    if "ofast" in only:
+        os.makedirs(os.path.join(HERE, "ofast"), exist_ok=True)
+        for name in OFAST_CONFIGS:
+            out = os.path.join(HERE, "ofast", name + ".png")
+            timings["ofast/" + name + ".png"] = run([REF_EXE_FAST, os.path.join(SCENES, CONFIGS[name][0]), out])
+            print(name, "ofast png done %.1fs" % timings["ofast/" + name + ".png"], flush=True)
     meta_path = os.path.join(HERE, "MANIFEST.json")
     meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
+    if "ofast" in only:
+        cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")]
+        meta["reference_build_ofast"] = ("g++ (Ubuntu 11.4.0-1ubuntu1~22.04.2) 11.4.0, -Ofast -flto -march=native -std=c++17 -pthread "
+                                         "(the reference Makefile's flags) on " + (cpu[0] if cpu else "unknown CPU"))
     meta.update({
         "reference_build": "g++ (Ubuntu 11.4.0-1ubuntu1~22.04.2) 11.4.0, -O2 -std=c++17 -pthread (O-strict), glibc 2.35",
         "hue_table": "int-abs (printed by `ref_harness hues`)",

@@ -195,6 +195,33 @@ def test_c5_caustic_frames(hip_ctx, frame):
     assert d["frac_gt1"] == 0.0
 
 
+# The reference built with its OWN Makefile flags (-Ofast -flto -march=native) is the secondary parity
+# target: fast-math reorders its arithmetic, so the bar against it is the reference's own
+# flag noise — what its O-strict and O-fast builds differ by (tests/test_oracle_golden.py asserts those
+# numbers on the two sets of reference files).  Bounds: (fraction of pixels beyond 1 LSB, PSNR dB).
+OFAST = [
+    ("c1_example1", "examples/example1.xml", 0, 0.0, 99.0),
+    ("c2_example9_lowres", "examples/example9_lowres.xml", 0, 0.001, 60.0),
+    ("c3_fresnel", "examples2/8_fresnel.xml", 0, 0.0, 80.0),
+    ("c4_julia_shiny", "examples3/101_julia_shiny.xml", 0, 0.0025, 55.0),   # the reference's own builds differ by 0.19 % here
+    ("c5_caustic_animation", "examples3/103_caustic_animation.xml", 10, 0.001, 65.0),
+]
+
+
+@pytest.mark.parametrize("name,rel,frame,max_gt1,min_psnr", OFAST)
+def test_secondary_target_reference_built_with_its_own_flags(hip_ctx, name, rel, frame, max_gt1, min_psnr):
+    t = float(np.float32(frame) / np.float32(19))
+    img, _ = hip_render(hip_ctx, capi.Scene(scene_path(rel), t))
+    fast, _n = capi.png_read(golden_path("ofast/" + name + ".png"), frame)
+    d = oracle_lib.image_diff(capi.quantize(img), fast)
+    print(name, d)
+    assert d["frac_gt1"] <= max_gt1 and d["psnr"] >= min_psnr, (name, d)
+    # and never further from it than the reference's own O-strict build is
+    strict, _n = capi.png_read(golden_path(name + ".png"), frame)
+    d0 = oracle_lib.image_diff(strict, fast)
+    assert d["frac_gt1"] <= d0["frac_gt1"] + 1e-4 and d["psnr"] >= d0["psnr"] - 0.5, (name, d, d0)
+
+
 def test_photon_atlas_vs_oracle(hip_ctx):
     sc = capi.Scene(scene_path("examples3/103_caustic_steps200.xml"), 0.5)
     hip_ctx.upload(sc)

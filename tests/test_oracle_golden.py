@@ -75,6 +75,25 @@ def test_oracle_full_image_matches_reference_png():
     assert np.array_equal(capi.quantize(img), ref)
 
 
+# SURVEY 8c names two reference builds: O-strict (primary, bit-exact above) and the Makefile's own
+# -Ofast -flto -march=native (secondary; tests/golden/ofast/, host-dependent).  What the reference's two
+# builds differ by is the noise floor of any comparison with the second one; DESIGN.md section 2 quotes
+# these numbers and the GPU suite holds the HIP path to them.
+@pytest.mark.parametrize("name,frames,max_gt1,min_psnr", [
+    ("c1_example1", [0], 0.0, 99.0),
+    ("c2_example9_lowres", [0], 0.001, 60.0),
+    ("c3_fresnel", [0], 0.0, 80.0),
+    ("c4_julia_shiny", [0], 0.0025, 55.0),       # beyond the north star's 0.1 %: the reference against itself
+    ("c5_caustic_animation", list(range(20)), 0.001, 65.0),
+])
+def test_reference_flag_noise_between_its_two_builds(name, frames, max_gt1, min_psnr):
+    for f in frames:
+        strict, _ = capi.png_read(golden_path(name + ".png"), f)
+        fast, _ = capi.png_read(golden_path("ofast/" + name + ".png"), f)
+        d = oracle_lib.image_diff(strict, fast)
+        assert d["frac_gt1"] <= max_gt1 and d["psnr"] >= min_psnr, (name, f, d)
+
+
 def test_kat_records_bit_exact():
     # Object::intersect and calcFresnel answers written by the reference through ref_harness
     for name in ("c2_example9_lowres", "c4_julia_shiny", "c3_fresnel", "x_transparent"):
