@@ -212,6 +212,17 @@ int rt_render_device(rt_ctx* ctx, const rt_bands* bands_or_null, void* d_rgba_ou
 int rt_photon_generate_device(rt_ctx* ctx, void* hip_stream);
 int rt_fetch_stats(rt_ctx* ctx, rt_stats* out);
 
+/* One photon pass split over several GPUs: emits only slice `part` of `n_parts` equal
+ * contiguous slices of the root-photon sequence of PhotonMapper::generate (reference
+ * src/photonmap.cpp:32-56: point lights in scene order, then phi, theta, hue) into this context's
+ * zeroed photon textures.  The caller then SUMS the textures of all parts — rt_photon_atlas_device
+ * gives the device buffer (all receivers' textures, contiguous floats) for an in-place all-reduce —
+ * before any rt_render.  part 0 of 1 is rt_photon_generate_device.  The reference's pass is
+ * single-threaded; the sum of the parts equals its textures up to the order of the float additions
+ * (as rt_photon_generate itself, whose deposits are float atomics). */
+int rt_photon_generate_part_device(rt_ctx* ctx, void* hip_stream, uint32_t part, uint32_t n_parts);
+int rt_photon_atlas_device(rt_ctx* ctx, void** d_atlas_out, uint64_t* n_floats_out);
+
 /* Test hook: copies the photon texture of scene object `object_index` (texture_size^2 RGBA floats;
  * zeros if the object is not a diffuse receiver).  ≙ Object::getPhoton, reference src/objects.cpp:257-267 */
 int rt_photon_download(rt_ctx* ctx, uint32_t object_index, float* rgba_out);

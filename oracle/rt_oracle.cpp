@@ -565,8 +565,10 @@ struct PhotonTracer {
         cast_ray(Tracer::reflection_ray(ray, hit, cos_rn), recursion + 1, wavelength, cmul(rad, kr));
     }
 
-    // src/photonmap.cpp:20-59
-    void generate() {
+    // src/photonmap.cpp:20-59.  [begin, end) selects a slice of the root-photon sequence (test support for the
+    // multi-GPU split of one pass, rt_photon_generate_part_device); the default is the whole pass.
+    void generate(uint64_t begin = 0, uint64_t end = UINT64_MAX) {
+        uint64_t root = 0;
         for (uint32_t li = 0; li < sc.n_lights; li++) {
             const rt_light& light = sc.lights[li];
             if (light.type == RT_LIGHT_PARALLEL) continue;
@@ -577,16 +579,29 @@ struct PhotonTracer {
                     const Ray ray = make_ray(v3(light.position), dir);
                     if (sc.dispersion_mode) {
                         int hue_index = 0;
-                        for (float hue = 0.0f; hue < 360.0f; hue += 45.0f, hue_index++) {
+                        for (float hue = 0.0f; hue < 360.0f; hue += 45.0f, hue_index++, root++) {
+                            if (root < begin || root >= end) continue;
                             const Col hue_color = {sc.hue_rgb[hue_index][0], sc.hue_rgb[hue_index][1], sc.hue_rgb[hue_index][2], 1.0f};
                             cast_ray(ray, 0, hue / 180.0f - 1.0f, cdiv(cmul(hue_color, sc.photon_factor), 4));
                         }
                     } else {
-                        cast_ray(ray, 0, 0, cmul(Col{1.0f, 1.0f, 1.0f, 1.0f}, sc.photon_factor));
+                        if (root >= begin && root < end) cast_ray(ray, 0, 0, cmul(Col{1.0f, 1.0f, 1.0f, 1.0f}, sc.photon_factor));
+                        root++;
                     }
                 }
             }
         }
+    }
+
+    // number of root photons of the whole pass (the trip counts of the float loops above)
+    uint64_t count_roots() const {
+        uint64_t lights = 0;
+        for (uint32_t li = 0; li < sc.n_lights; li++) lights += sc.lights[li].type != RT_LIGHT_PARALLEL;
+        const float step = 2 * PI_F / sc.photon_steps;
+        uint64_t n_phi = 0, n_theta = 0;
+        for (float phi = 0.0f; phi < 2 * PI_F; phi += step) n_phi++;
+        for (float theta = 0.0f; theta < PI_F; theta += step) n_theta++;
+        return lights * n_phi * n_theta * (sc.dispersion_mode ? 8 : 1);
     }
 };
 
@@ -631,6 +646,31 @@ oracle_photons* oracle_photon_generate(const rt_scene_desc* sc, rt_stats* stats)
         export_counters(Counters{}, stats);
     }
     return p;
+}
+
+// Slice `part` of `n_parts` of the pass (as rt_photon_generate_part_device splits it)
+oracle_photons* oracle_photon_generate_part(const rt_scene_desc* sc, uint32_t part, uint32_t n_parts, rt_stats* stats) {
+    auto* p = new oracle_photons;
+    p->maps.size = sc->photon_texture_size;
+    p->maps.per_object.resize(sc->n_objects);
+    if (sc->photon_steps > 0.0f && n_parts > 0 && part < n_parts) {
+        PhotonTracer tracer(*sc, p->maps);
+        const uint64_t all = tracer.count_roots();
+        tracer.generate(all * part / n_parts, all * (part + 1) / n_parts);
+        export_counters(tracer.geo.n, stats);
+    } else {
+        export_counters(Counters{}, stats);
+    }
+    return p;
+}
+
+// Replaces the texture of object `object_index` (texture_size^2 RGBA floats): the stand-in for the
+// all-reduced atlas in the multi-rank driver tests
+void oracle_photon_set(oracle_photons* p, uint32_t object_index, const float* rgba) {
+    const size_t n = size_t(p->maps.size) * p->maps.size;
+    std::vector<Col>& tex = p->maps.per_object[object_index];
+    tex.resize(n);
+    std::memcpy(tex.data(), rgba, n * 4 * sizeof(float));
 }
 
 void oracle_photon_free(oracle_photons* p) { delete p; }

@@ -261,6 +261,8 @@ def hip_lib():
         lib.rt_render.argtypes = [C.c_void_p, C.POINTER(Bands), C.c_void_p, C.POINTER(Stats)]
         lib.rt_render_device.argtypes = [C.c_void_p, C.POINTER(Bands), C.c_void_p, C.c_void_p]
         lib.rt_photon_generate_device.argtypes = [C.c_void_p, C.c_void_p]
+        lib.rt_photon_generate_part_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.rt_photon_atlas_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         lib.rt_fetch_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         lib.rt_photon_download.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         lib.rt_mul_add_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint64, C.c_void_p]
@@ -321,6 +323,16 @@ class Context:
 
     def photon_generate_device(self, stream=None):
         self._check(self._lib.rt_photon_generate_device(self._ctx, C.c_void_p(stream or 0)), "rt_photon_generate_device")
+
+    def photon_generate_part_device(self, part, n_parts, stream=None):
+        self._check(self._lib.rt_photon_generate_part_device(self._ctx, C.c_void_p(stream or 0), part, n_parts),
+                    "rt_photon_generate_part_device")
+
+    def photon_atlas_device(self):
+        """(device pointer, number of floats) of all photon textures of the uploaded scene; (0, 0) without receivers."""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.rt_photon_atlas_device(self._ctx, C.byref(ptr), C.byref(n)), "rt_photon_atlas_device")
+        return ptr.value or 0, n.value
 
     def fetch_stats(self):
         st = Stats()

@@ -250,7 +250,7 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     return RT_OK;
 }
 
-int photon_enqueue(rt_ctx* ctx, hipStream_t stream) {
+int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t n_parts = 1) {
     if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_photon_generate before rt_scene_upload");
     RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long), stream));
     RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
@@ -268,7 +268,14 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream) {
         job.n_point_lights = static_cast<uint32_t>(ctx->point_lights.size());
         job.point_lights = ctx->d_point_lights;
         job.hues = ctx->hues;
-        job.n_roots = static_cast<uint64_t>(job.n_point_lights) * job.n_phi * job.n_theta * job.hues;
+        const uint64_t all_roots = static_cast<uint64_t>(job.n_point_lights) * job.n_phi * job.n_theta * job.hues;
+        job.root_base = all_roots * part / n_parts;
+        job.n_roots = all_roots * (part + 1) / n_parts - job.root_base;
+        if (job.n_roots == 0) {   // more parts than roots
+            RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream));
+            ctx->events_pending = true;
+            return RT_OK;
+        }
         const bool julia = ctx->dev.n_julias > 0;
         const bool stats = ctx->collect_stats;
         int blocks = 0;
@@ -819,6 +826,21 @@ int rt_photon_generate_device(rt_ctx* ctx, void* hip_stream) {
     if (ctx == nullptr) return RT_ERR_INVALID_ARGUMENT;
     RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return photon_enqueue(ctx, static_cast<hipStream_t>(hip_stream));
+}
+
+int rt_photon_generate_part_device(rt_ctx* ctx, void* hip_stream, uint32_t part, uint32_t n_parts) {
+    if (ctx == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    if (n_parts == 0 || part >= n_parts) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_photon_generate_part_device: part must be < n_parts");
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return photon_enqueue(ctx, static_cast<hipStream_t>(hip_stream), part, n_parts);
+}
+
+int rt_photon_atlas_device(rt_ctx* ctx, void** d_atlas_out, uint64_t* n_floats_out) {
+    if (ctx == nullptr || d_atlas_out == nullptr || n_floats_out == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_photon_atlas_device before rt_scene_upload");
+    *d_atlas_out = ctx->dev.photon_atlas;
+    *n_floats_out = ctx->dev.photon_atlas == nullptr ? 0 : static_cast<uint64_t>(ctx->n_slots) * ctx->dev.photon_size * ctx->dev.photon_size * 4;
+    return RT_OK;
 }
 
 int rt_photon_generate(rt_ctx* ctx, rt_stats* stats) {

@@ -1299,6 +1299,7 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
             if (need) {
                 need = false;
                 if (got) {
+                    id += job.root_base;
                     const unsigned hue = static_cast<unsigned>(id % job.hues);
                     unsigned long long q = id / job.hues;
                     const unsigned ti = static_cast<unsigned>(q % job.n_theta);

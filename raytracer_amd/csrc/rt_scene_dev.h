@@ -173,7 +173,8 @@ struct DevPhotonJob {
     uint32_t n_point_lights;
     const uint32_t* point_lights;   // indices into lights
     uint32_t hues;                  // 8 in dispersion mode else 1
-    uint64_t n_roots;               // n_point_lights*n_phi*n_theta*hues
+    uint64_t n_roots;               // roots this launch emits (all of n_point_lights*n_phi*n_theta*hues, or one slice of them)
+    uint64_t root_base;             // first root of the slice (rt_photon_generate_part_device)
     float* stack;
     unsigned long long* queue_head;
     unsigned long long* counters;

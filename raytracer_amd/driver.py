@@ -1,13 +1,17 @@
 """Multi-GPU render driver: the reference's four render loops (src/main.cpp:14-158), sharded.
 
 One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
-the CPU tests).  There is no exchange during compute: the only collective is the gather
-of finished pictures to rank 0, which alone accumulates motion blur (in sub-frame order, so the
-rounding is the reference's Picture::mulAdd order) and writes the PNG/APNG.
+the CPU tests).  There is no exchange during the trace: finished pictures are gathered to rank 0, which
+alone accumulates motion blur (in sub-frame order, so the rounding is the reference's Picture::mulAdd
+order) and writes the PNG/APNG.  The one real exchange step is the photon pass of a STILL: all ranks
+work on the same frame, so each emits a slice of the root photons and the photon textures are summed
+with one all-reduce (≤ 7 MB) before the bands are traced; frames of an animation keep their photon
+pass whole on the rank that renders the frame.
 
   stills                 8-row bands of the image, interleaved over the ranks (per-pixel cost is very
                          uneven on Julia scenes; the reference hands out single rows dynamically,
-                         src/raytracer.cpp:48-53)
+                         src/raytracer.cpp:48-53); photon pass split over the ranks + all-reduce when
+                         it is large enough to pay (SPLIT_PHOTON_MIN_STEPS, or RT_SPLIT_PHOTONS=0/1)
   still + motion blur    sub-frames round-robin over the ranks
   animation              frames round-robin over the ranks, RGBA8 frames gathered
   animation + blur       (frame, sub-frame) pairs round-robin over the ranks
@@ -25,6 +29,16 @@ import torch.distributed as dist
 from . import capi
 
 BAND_ROWS = 8
+# <caustic steps> from which a still's photon pass is split over the ranks: 1000 steps = 500 000 directions
+# per light (0.6 ms on one MI355X at C5's size, against some 50 us for the all-reduce of the textures)
+SPLIT_PHOTON_MIN_STEPS = 1000.0
+
+
+class _DeviceFloats:
+    """Device memory owned by the C library, described for torch.as_tensor (no copy)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
 
 class HipRenderer:
@@ -35,11 +49,23 @@ class HipRenderer:
         torch.cuda.set_device(self.device)
         self.ctx = capi.Context(device_index)
 
-    def render(self, scene, bands=None):
+    def photon_pass(self, scene, part, n_parts):
+        """Uploads the scene and emits slice `part` of `n_parts` of its photon pass.  Returns the photon
+        textures as a flat float tensor ALIASING the context's device buffer (None without receivers):
+        the caller sums it over the ranks in place, then calls render(..., photons_ready=True)."""
         self.ctx.upload(scene)
+        self.ctx.photon_generate_part_device(part, n_parts, torch.cuda.current_stream().cuda_stream)
+        ptr, n = self.ctx.photon_atlas_device()
+        if n == 0:
+            return None
+        return torch.as_tensor(_DeviceFloats(ptr, n), device=self.device)
+
+    def render(self, scene, bands=None, photons_ready=False):
         stream = torch.cuda.current_stream().cuda_stream
-        if scene.desc.photon_steps > 0:
-            self.ctx.photon_generate_device(stream)
+        if not photons_ready:      # (an upload clears the photon textures)
+            self.ctx.upload(scene)
+            if scene.desc.photon_steps > 0:
+                self.ctx.photon_generate_device(stream)
         n = self.ctx.pixel_count(bands)
         out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         if n:
@@ -115,12 +141,30 @@ def motion_blur_units(path, info, load=capi.Scene):
 
 # ---------------------------------------------------------------------------------- the loops
 
+def split_photon_pass(scene, world):
+    """Whether the ranks share one photon pass (stills only).  RT_SPLIT_PHOTONS=0/1 overrides."""
+    if world <= 1 or scene.desc.photon_steps <= 0:
+        return False
+    forced = os.environ.get("RT_SPLIT_PHOTONS")
+    if forced is not None:
+        return forced not in ("", "0")
+    return scene.desc.photon_steps >= SPLIT_PHOTON_MIN_STEPS
+
+
 def render_still(renderer, scene):
     """One picture, bands interleaved over the ranks; returns the full [H,W,4] float picture on rank 0."""
     rank, world = world_info()
     h, w = scene.height, scene.width
     bands = capi.Bands(BAND_ROWS, rank, world)
-    part = renderer.render(scene, bands)
+    if split_photon_pass(scene, world):
+        # PhotonMapper::generate (src/photonmap.cpp:32-56) once for the whole job: rank r emits the r-th slice
+        # of the root photons, the deposits of all slices are summed into every rank's textures
+        atlas = renderer.photon_pass(scene, rank, world)
+        if atlas is not None:
+            dist.all_reduce(atlas, op=dist.ReduceOp.SUM)
+        part = renderer.render(scene, bands, photons_ready=True)
+    else:
+        part = renderer.render(scene, bands)
     # pad to the largest share so that the gather has equal shapes
     n_max = max(len(band_rows_of(h, r, world)) for r in range(world)) * w
     padded = torch.zeros((n_max, 4), dtype=part.dtype, device=part.device)

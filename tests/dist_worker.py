@@ -18,8 +18,17 @@ class OracleRenderer:
     """Same interface as driver.HipRenderer, computing with the CPU oracle (test stand-in only)."""
     device = torch.device("cpu")
 
-    def render(self, scene, bands=None):
-        photons = oracle_lib.Photons(scene) if scene.desc.photon_steps > 0 else None
+    def photon_pass(self, scene, part, n_parts):
+        self._photons = oracle_lib.Photons(scene, part, n_parts)
+        self._atlas = torch.from_numpy(self._photons.atlas())
+        return self._atlas.reshape(-1)       # a view: the all-reduce lands in self._atlas
+
+    def render(self, scene, bands=None, photons_ready=False):
+        if photons_ready:
+            self._photons.set_atlas(self._atlas.numpy())
+            photons = self._photons
+        else:
+            photons = oracle_lib.Photons(scene) if scene.desc.photon_steps > 0 else None
         h, w = scene.height, scene.width
         if bands is None:
             img, _ = oracle_lib.render(scene, photons, threads=2)

@@ -18,6 +18,9 @@ def lib():
         l = C.CDLL(ORACLE_LIB_PATH)
         l.oracle_photon_generate.restype = C.c_void_p
         l.oracle_photon_generate.argtypes = [C.POINTER(capi.SceneDesc), C.POINTER(capi.Stats)]
+        l.oracle_photon_generate_part.restype = C.c_void_p
+        l.oracle_photon_generate_part.argtypes = [C.POINTER(capi.SceneDesc), C.c_uint32, C.c_uint32, C.POINTER(capi.Stats)]
+        l.oracle_photon_set.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         l.oracle_photon_free.argtypes = [C.c_void_p]
         l.oracle_photon_get.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         l.oracle_render.argtypes = [C.POINTER(capi.SceneDesc), C.c_void_p, C.c_int, C.c_void_p, C.POINTER(capi.Stats)]
@@ -34,10 +37,22 @@ def lib():
 
 
 class Photons:
-    def __init__(self, scene):
+    def __init__(self, scene, part=None, n_parts=1):
         self.stats = capi.Stats()
         self.scene = scene
-        self._h = lib().oracle_photon_generate(C.byref(scene.desc), C.byref(self.stats))
+        if part is None:
+            self._h = lib().oracle_photon_generate(C.byref(scene.desc), C.byref(self.stats))
+        else:   # one slice of the pass, as rt_photon_generate_part_device splits it
+            self._h = lib().oracle_photon_generate_part(C.byref(scene.desc), part, n_parts, C.byref(self.stats))
+
+    def atlas(self):
+        """All textures, [n_objects, size, size, 4] (zeros for objects that received nothing)."""
+        return np.stack([self.texture(i) for i in range(self.scene.desc.n_objects)])
+
+    def set_atlas(self, atlas):
+        a = np.ascontiguousarray(atlas, dtype=np.float32)
+        for i in range(self.scene.desc.n_objects):
+            lib().oracle_photon_set(self._h, i, a[i].ctypes.data)
 
     def texture(self, object_index):
         size = self.scene.desc.photon_texture_size

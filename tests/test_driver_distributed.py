@@ -37,9 +37,9 @@ def small_scene(tmp_path, extra_scene_tags="", camera_pos='x="0;1.5(b)" y="0;1(b
     return str(xml)
 
 
-def run_two_ranks(scene, tmp_path):
+def run_two_ranks(scene, tmp_path, **extra_env):
     out, result = str(tmp_path / "dist.png"), str(tmp_path / "dist.npy")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29611", os.path.join(ROOT, "tests", "dist_worker.py"), scene, out, result]
     subprocess.run(cmd, check=True, env=env, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
@@ -88,6 +88,33 @@ def test_two_ranks_equal_one(tmp_path, kind, tags):
     for i, b in enumerate(want):
         img, n = capi.png_read(png, i)
         assert n == len(want) and np.array_equal(img, b)
+
+
+def test_two_ranks_share_one_photon_pass(tmp_path):
+    """A still whose photon pass is split over the ranks (each emits half of the root photons, the photon
+    textures are summed with an all-reduce, then each rank traces its bands).  The sum of two partial
+    sums is not the reference's sequential sum bit for bit: the picture agrees to float rounding."""
+    scene = small_scene(tmp_path, "", steps=90)
+    sc = capi.Scene(scene, 0.0)
+    # the slices partition the pass: same deposits, and the summed textures are the whole pass's to rounding
+    whole = oracle_lib.Photons(sc)
+    halves = [oracle_lib.Photons(sc, part, 2) for part in range(2)]
+    assert sum(h.stats.photon_deposits for h in halves) == whole.stats.photon_deposits > 0
+    assert sum(h.stats.photon_segments for h in halves) == whole.stats.photon_segments
+    total = halves[0].atlas() + halves[1].atlas()
+    assert np.allclose(total, whole.atlas(), rtol=1e-5, atol=1e-7) and whole.atlas().max() > 0
+    one = oracle_lib.Photons(sc, 0, 1)
+    assert np.array_equal(one.atlas(), whole.atlas())
+    # through the driver on two ranks
+    got, _png = run_two_ranks(scene, tmp_path, RT_SPLIT_PHOTONS="1")
+    want = single_process_frames(scene)
+    assert len(got) == len(want) == 1
+    d = oracle_lib.image_diff(got[0], want[0])
+    assert d["max"] <= 1 and d["frac_gt0"] < 1e-3, d
+    # and the policy: small passes stay whole on every rank, large ones are shared
+    assert not driver.split_photon_pass(sc, 2) and not driver.split_photon_pass(sc, 1)
+    big = capi.Scene(scene_path("examples3/103_caustic_animation.xml"), 0.0)
+    assert driver.split_photon_pass(big, 8) and not driver.split_photon_pass(big, 1)
 
 
 def test_schedules():

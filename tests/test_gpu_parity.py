@@ -6,6 +6,7 @@ for operation, so against the oracle the tests also assert the much tighter boun
 reach (bit-exact float32 except where float atomics reorder photon sums).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -193,6 +194,69 @@ def test_c5_caustic_frames(hip_ctx, frame):
     assert n == 20
     d = assert_north_star(capi.quantize(img), gold, "c5 frame %d" % frame)
     assert d["frac_gt1"] == 0.0
+
+
+def test_photon_pass_in_slices_sums_to_the_whole(hip_ctx):
+    """rt_photon_generate_part_device (the multi-GPU split of one pass): three slices emitted into three
+    contexts, textures summed through the tensors that alias the device buffers (what the driver's
+    all-reduce does in place), against the whole pass and against the oracle; then a render from the
+    summed textures against the render after the whole pass."""
+    import torch
+    from raytracer_amd import driver
+    sc = capi.Scene(scene_path("examples3/103_caustic_steps200.xml"), 0.5)
+    ref_img, _ = hip_render(hip_ctx, sc)
+    ptr, n = hip_ctx.photon_atlas_device()
+    assert n > 0
+    whole = torch.as_tensor(driver._DeviceFloats(ptr, n), device="cuda").clone()
+    parts = [driver.HipRenderer(0) for _ in range(3)]
+    tensors = [r.photon_pass(sc, i, 3) for i, r in enumerate(parts)]
+    assert all(t.numel() == n for t in tensors)
+    torch.cuda.synchronize()
+    assert all(float(t.abs().sum()) > 0 for t in tensors)          # every slice deposits something here
+    tensors[0] += tensors[1]
+    tensors[0] += tensors[2]
+    assert torch.allclose(tensors[0], whole, rtol=2e-5, atol=1e-7)
+    img = parts[0].render(sc, None, photons_ready=True).cpu().numpy().reshape(ref_img.shape)
+    assert np.allclose(img, ref_img, rtol=1e-5, atol=1e-7)
+    assert_north_star(capi.quantize(img), capi.quantize(ref_img), "summed slices")
+    # against the oracle's slices: same number of deposits per slice
+    hip_ctx.set_option(capi.RT_OPT_COLLECT_STATS, 1)
+    for i in range(3):
+        hip_ctx.upload(sc)
+        hip_ctx.photon_generate_part_device(i, 3)
+        torch.cuda.synchronize()
+        st = hip_ctx.fetch_stats()
+        want = oracle_lib.Photons(sc, i, 3).stats
+        assert (st.photon_deposits, st.photon_segments) == (want.photon_deposits, want.photon_segments), i
+    hip_ctx.set_option(capi.RT_OPT_COLLECT_STATS, 0)
+    # invalid slices are refused
+    with pytest.raises(RuntimeError):
+        hip_ctx.photon_generate_part_device(3, 3)
+
+
+def test_rccl_all_reduce_on_the_library_owned_photon_textures(hip_ctx):
+    """The driver all-reduces the photon textures in place, in memory the C library allocated (not torch's
+    allocator).  One-rank RCCL group on this box: the collective must accept that buffer and leave the
+    single contribution unchanged; the two-rank arithmetic is covered on CPU (gloo) and by the test above."""
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import driver
+    sc = capi.Scene(scene_path("examples3/103_caustic_steps200.xml"), 0.5)
+    r = driver.HipRenderer(0)
+    atlas = r.photon_pass(sc, 0, 1)
+    before = atlas.clone()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29643")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        dist.all_reduce(atlas, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        assert torch.equal(atlas, before) and float(before.sum()) > 0
+        full = driver.render_still(r, sc)          # world 1: whole pass, no split
+        img, _ = hip_render(hip_ctx, sc)
+        assert np.allclose(full.cpu().numpy(), img, rtol=1e-5, atol=1e-7)
+    finally:
+        dist.destroy_process_group()
 
 
 # The reference built with its OWN Makefile flags (-Ofast -flto -march=native) is the secondary parity
