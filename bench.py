@@ -248,7 +248,7 @@ def main():
             "config": {"workload": label, "scene": rel, "t": t, "rays_per_frame": rays_per_step,
                        "frames_per_step": world, "sec_per_frame": elapsed / args.steps,
                        "parallelism": "frames sharded over ranks, RGBA8 frames gathered to rank 0 over RCCL (gather of a step overlaps the next step's render; all gathers complete inside the timed region)" if world > 1 else "1 GPU"},
-            "roofline": {"bound": "valu", "kernel": "trace_kernel", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
+            "roofline": {"bound": "valu", "kernel": "trace_julia_kernel" if scene.desc.n_julias > 0 else "trace_kernel", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": measured_traffic(args.workload),
                          "frac_of_unfused_issue_ceiling": achieved / ISSUE_CEILING_TFLOPS,
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops_per_step,

@@ -190,7 +190,14 @@ enum {
     RT_OPT_COLLECT_STATS = 1,   /* 0/1: fill rt_stats counters (slower kernels); default 0 */
     RT_OPT_BVH_MIN_TRIANGLES = 2,/* BVH traversal for runs of consecutive triangle objects of at least this many (default 256);
                                     runs holding a zero-area triangle always keep the sequential scan */
-    RT_OPT_DOF_SEED = 3         /* seed of the counter-based lens RNG; default 0 */
+    RT_OPT_DOF_SEED = 3,        /* seed of the counter-based lens RNG; default 0 */
+    RT_OPT_PHOTON_ORDER = 4,    /* 1 (default): photon deposits are recorded, sorted and summed per texel in the order of the
+                                   reference's sequential pass (src/photonmap.cpp:32-56, src/objects.cpp:244-256): textures
+                                   bit-identical to the reference's.  0: float atomics, textures equal to rounding (fastest).
+                                   rt_photon_generate_device on a scene whose deposits outgrow the record buffer adds the
+                                   surplus with atomics and sizes the buffer for the next pass; rt_photon_generate reruns. */
+    RT_OPT_PHOTON_RECORDS = 5   /* capacity of that record buffer in deposits; 0 (default) = an eighth of the root photons,
+                                   at least 262144; grows by itself as described above */
 };
 int rt_set_option(rt_ctx* ctx, int option, int64_t value);
 
@@ -219,7 +226,7 @@ int rt_fetch_stats(rt_ctx* ctx, rt_stats* out);
  * gives the device buffer (all receivers' textures, contiguous floats) for an in-place all-reduce —
  * before any rt_render.  part 0 of 1 is rt_photon_generate_device.  The reference's pass is
  * single-threaded; the sum of the parts equals its textures up to the order of the float additions
- * (as rt_photon_generate itself, whose deposits are float atomics). */
+ * (within a slice the deposits keep the reference's order, RT_OPT_PHOTON_ORDER). */
 int rt_photon_generate_part_device(rt_ctx* ctx, void* hip_stream, uint32_t part, uint32_t n_parts);
 int rt_photon_atlas_device(rt_ctx* ctx, void** d_atlas_out, uint64_t* n_floats_out);
 

@@ -17,7 +17,7 @@ RT_ABI_VERSION = 1
 RT_OBJ_SPHERE, RT_OBJ_TRIANGLE, RT_OBJ_JULIA = 0, 1, 2
 RT_LIGHT_PARALLEL, RT_LIGHT_POINT = 0, 1
 RT_HUE_INT_ABS, RT_HUE_FLOAT_ABS = 0, 1
-RT_OPT_COLLECT_STATS, RT_OPT_BVH_MIN_TRIANGLES, RT_OPT_DOF_SEED = 1, 2, 3
+RT_OPT_COLLECT_STATS, RT_OPT_BVH_MIN_TRIANGLES, RT_OPT_DOF_SEED, RT_OPT_PHOTON_ORDER, RT_OPT_PHOTON_RECORDS = 1, 2, 3, 4, 5
 RT_DEFAULT_BVH_MIN_TRIANGLES = 256
 FLT_MAX = float(np.finfo(np.float32).max)
 

@@ -30,6 +30,10 @@ __global__ void kat_fresnel_kernel(const float* in, unsigned n, float* out);
 __global__ void mul_add_kernel(float* acc, const float* src, float factor, unsigned long long n);
 __global__ void quantize_kernel(const float4* rgba, uchar4* out, float gain, unsigned long long n);
 hipError_t build_triangle_bvh(const DevTriTest* tris, uint32_t first, uint32_t n, DevBvhNode* nodes);
+hipError_t photon_order_temp_bytes(unsigned capacity, unsigned key_bits, size_t* bytes);
+hipError_t photon_order_reduce(const unsigned long long* keys, const float4* vals, unsigned capacity, unsigned key_bits, unsigned texel_shift,
+                               unsigned long long n_texels, float4* atlas, unsigned long long* sorted_keys, unsigned* sorted_index,
+                               unsigned* long_runs, unsigned long long* words, void* temp, size_t temp_bytes, hipStream_t stream);
 constexpr int kFrameFieldsHost = 11;
 constexpr size_t kMaxLdsBlobBytes = 28 * 1024;   // + 11 KB of frame tops: keeps 4 blocks per CU within the 160 KB LDS
 constexpr size_t kMaxLdsBlobBytesJulia = 24 * 1024;   // trace_julia_kernel: one workgroup per CU, 68 KB of its own LDS   // trace_julia_kernel: blob + its queues stay under 64 KB
@@ -71,6 +75,16 @@ struct rt_ctx {
     bool collect_stats = false;
     int64_t bvh_min_triangles = 256;  // below this the chunk-culled scan wins (C2, 64 triangles: 2.9 ms against 3.9 ms with the BVH)
     uint32_t dof_seed = 0;
+    bool photon_order = true;          // RT_OPT_PHOTON_ORDER: deposits summed in the reference's order
+    // ordered photon deposits (rt_photon_order.hip)
+    Buffer dep_keys, dep_vals, dep_sorted_keys, dep_sorted_index, dep_long_runs, dep_temp;
+    uint32_t dep_capacity = 0;         // records; 0 = choose from the number of roots
+    size_t dep_temp_bytes = 0;
+    unsigned long long* d_dep_words = nullptr;   // [0] records reserved, [1] deposits that found the buffer full, [2] long runs
+    unsigned long long* h_dep_words = nullptr;   // pinned copy, written by the stream after every ordered pass
+    hipEvent_t ev_dep = nullptr;
+    bool dep_check_pending = false;
+    bool dep_last_pass_ordered = false;
     // per-call scratch, grown on demand and kept
     Buffer samples, stack, out_staging, kat_a, kat_b, kat_c, kat_d;
     unsigned long long* d_queue = nullptr;      // [0] = queue head
@@ -250,6 +264,47 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     return RT_OK;
 }
 
+unsigned bit_width(unsigned long long v) {
+    unsigned n = 0;
+    while (v != 0) {
+        n++;
+        v >>= 1;
+    }
+    return n;
+}
+
+// Looks at what the last ordered photon pass reported (pinned words, written by its stream) once that pass
+// has completed, and sizes the record buffer for the next one.  Returns true if that pass ran out of
+// records (its surplus deposits were added with float atomics: correct to rounding, not bit for bit).
+bool deposit_overflow_seen(rt_ctx* ctx) {
+    if (!ctx->dep_check_pending || hipEventQuery(ctx->ev_dep) != hipSuccess) return false;
+    ctx->dep_check_pending = false;
+    if (ctx->h_dep_words[1] == 0) return false;
+    const unsigned long long wanted = ctx->h_dep_words[0] + ctx->h_dep_words[0] / 4;
+    ctx->dep_capacity = static_cast<uint32_t>(std::min<unsigned long long>((wanted + 65535ull) & ~65535ull, 1ull << 31));
+    return true;
+}
+
+int deposit_buffers(rt_ctx* ctx, unsigned long long all_roots, unsigned key_bits) {
+    (void)deposit_overflow_seen(ctx);
+    if (ctx->dep_capacity == 0) {
+        // C5: 8.0 M roots leave 0.37 M deposits; a wave reserves records kDepositChunk at a time
+        const unsigned long long guess = std::max<unsigned long long>(1ull << 18, all_roots / 8);
+        ctx->dep_capacity = static_cast<uint32_t>(std::min<unsigned long long>((guess + 65535ull) & ~65535ull, 1ull << 31));
+    }
+    const size_t n = ctx->dep_capacity;
+    int rc;
+    if ((rc = grow(ctx, ctx->dep_keys, n * sizeof(unsigned long long))) != RT_OK) return rc;
+    if ((rc = grow(ctx, ctx->dep_vals, n * sizeof(float4))) != RT_OK) return rc;
+    if ((rc = grow(ctx, ctx->dep_sorted_keys, n * sizeof(unsigned long long))) != RT_OK) return rc;
+    if ((rc = grow(ctx, ctx->dep_sorted_index, n * sizeof(unsigned))) != RT_OK) return rc;
+    if ((rc = grow(ctx, ctx->dep_long_runs, (n / kDepositLongRun + 1) * sizeof(unsigned))) != RT_OK) return rc;
+    size_t temp = 0;
+    RT_HIP_TRY(ctx, photon_order_temp_bytes(ctx->dep_capacity, key_bits, &temp));
+    ctx->dep_temp_bytes = temp;
+    return grow(ctx, ctx->dep_temp, temp ? temp : 1);
+}
+
 int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t n_parts = 1) {
     if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_photon_generate before rt_scene_upload");
     RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long), stream));
@@ -295,6 +350,23 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
         job.queue_head = ctx->d_queue;
         job.counters = ctx->d_counters;
         RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 2 * sizeof(unsigned long long), stream));
+        // reference deposit order: record, sort, sum (rt_photon_order.hip) when the key fits 64 bits
+        const unsigned long long n_texels = static_cast<unsigned long long>(ctx->n_slots) * ctx->dev.photon_size * ctx->dev.photon_size;
+        const unsigned texel_bits = bit_width(n_texels), root_bits = bit_width(all_roots), seq_bits = ctx->dev.max_bounces + 2;
+        const unsigned key_bits = texel_bits + root_bits + seq_bits;
+        const bool ordered = ctx->photon_order && key_bits <= 64;
+        ctx->dep_last_pass_ordered = ordered;
+        if (ordered) {
+            if ((rc = deposit_buffers(ctx, all_roots, key_bits)) != RT_OK) return rc;
+            job.dep_keys = static_cast<unsigned long long*>(ctx->dep_keys.ptr);
+            job.dep_vals = static_cast<float4*>(ctx->dep_vals.ptr);
+            job.dep_words = ctx->d_dep_words;
+            job.dep_capacity = ctx->dep_capacity;
+            job.dep_seq_bits = seq_bits;
+            job.dep_root_bits = root_bits;
+            RT_HIP_TRY(ctx, hipMemsetAsync(ctx->dep_keys.ptr, 0xFF, static_cast<size_t>(ctx->dep_capacity) * sizeof(unsigned long long), stream));
+            RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_dep_words, 0, 4 * sizeof(unsigned long long), stream));
+        }
         if (julia) {
             if (stats) hipLaunchKernelGGL((photon_kernel<true, true>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
             else hipLaunchKernelGGL((photon_kernel<true, false>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
@@ -303,6 +375,14 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
             else hipLaunchKernelGGL((photon_kernel<false, false>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
         }
         RT_HIP_TRY(ctx, hipGetLastError());
+        if (ordered) {
+            RT_HIP_TRY(ctx, photon_order_reduce(job.dep_keys, job.dep_vals, ctx->dep_capacity, key_bits, root_bits + seq_bits, n_texels, ctx->dev.photon_atlas,
+                                                static_cast<unsigned long long*>(ctx->dep_sorted_keys.ptr), static_cast<unsigned*>(ctx->dep_sorted_index.ptr),
+                                                static_cast<unsigned*>(ctx->dep_long_runs.ptr), ctx->d_dep_words, ctx->dep_temp.ptr, ctx->dep_temp_bytes, stream));
+            RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_dep_words, ctx->d_dep_words, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_dep, stream));
+            ctx->dep_check_pending = true;
+        }
     }
     RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream));
     ctx->events_pending = true;
@@ -383,6 +463,9 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
     ctx->n_cus = prop.multiProcessorCount;
     if (hipMalloc(reinterpret_cast<void**>(&ctx->d_queue), 256) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), C_COUNT * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&ctx->d_dep_words), 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&ctx->h_dep_words), 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipEventCreate(&ctx->ev_dep) != hipSuccess ||
         hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) {
         delete ctx;
         return fail(nullptr, RT_ERR_HIP, "cannot allocate context resources on device %d", device_id);
@@ -398,9 +481,13 @@ void rt_destroy(rt_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     free_scene(ctx);
-    for (Buffer* b : {&ctx->samples, &ctx->stack, &ctx->out_staging, &ctx->photon_tables, &ctx->kat_a, &ctx->kat_b, &ctx->kat_c, &ctx->kat_d}) {
+    for (Buffer* b : {&ctx->samples, &ctx->stack, &ctx->out_staging, &ctx->photon_tables, &ctx->kat_a, &ctx->kat_b, &ctx->kat_c, &ctx->kat_d,
+                      &ctx->dep_keys, &ctx->dep_vals, &ctx->dep_sorted_keys, &ctx->dep_sorted_index, &ctx->dep_long_runs, &ctx->dep_temp}) {
         if (b->ptr) (void)hipFree(b->ptr);
     }
+    if (ctx->d_dep_words) (void)hipFree(ctx->d_dep_words);
+    if (ctx->h_dep_words) (void)hipHostFree(ctx->h_dep_words);
+    if (ctx->ev_dep) (void)hipEventDestroy(ctx->ev_dep);
     if (ctx->d_point_lights) (void)hipFree(ctx->d_point_lights);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -415,6 +502,11 @@ int rt_set_option(rt_ctx* ctx, int option, int64_t value) {
         case RT_OPT_COLLECT_STATS: ctx->collect_stats = value != 0; return RT_OK;
         case RT_OPT_BVH_MIN_TRIANGLES: ctx->bvh_min_triangles = value; return RT_OK;
         case RT_OPT_DOF_SEED: ctx->dof_seed = static_cast<uint32_t>(value); return RT_OK;
+        case RT_OPT_PHOTON_ORDER: ctx->photon_order = value != 0; return RT_OK;
+        case RT_OPT_PHOTON_RECORDS:
+            if (value < 0 || value > (1ll << 31)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_PHOTON_RECORDS out of range");
+            ctx->dep_capacity = static_cast<uint32_t>((value + 63) & ~63ll);
+            return RT_OK;
         default: return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
     }
 }
@@ -844,9 +936,16 @@ int rt_photon_atlas_device(rt_ctx* ctx, void** d_atlas_out, uint64_t* n_floats_o
 }
 
 int rt_photon_generate(rt_ctx* ctx, rt_stats* stats) {
-    const int rc = rt_photon_generate_device(ctx, nullptr);
+    int rc = rt_photon_generate_device(ctx, nullptr);
     if (rc != RT_OK) return rc;
     RT_HIP_TRY(ctx, hipStreamSynchronize(nullptr));
+    if (deposit_overflow_seen(ctx)) {
+        // the record buffer was too small for this scene: it has been resized from what the pass reported;
+        // run the pass again so that the caller gets the reference's order
+        if ((rc = rt_photon_generate_device(ctx, nullptr)) != RT_OK) return rc;
+        RT_HIP_TRY(ctx, hipStreamSynchronize(nullptr));
+        if (deposit_overflow_seen(ctx)) return fail(ctx, RT_ERR_LIMIT, "photon deposits do not fit the record buffer (%llu wanted)", ctx->h_dep_words[0]);
+    }
     return read_stats(ctx, stats);
 }
 

@@ -1263,8 +1263,9 @@ __global__ __launch_bounds__(256) void sum_samples_kernel(const float4* __restri
 
 // ---- photon pass (src/photonmap.cpp:20-146) ---------------------------------------------------------
 // One lane = one root direction (light, phi, theta, hue).  The path tree is walked depth first with
-// a stack of pending rays; deposits are float atomics into the photon atlas (their order is not the
-// reference's sequential one: texels agree to rounding, not bit for bit).
+// a stack of pending rays.  Deposits are RECORDED with their position in the reference's sequential pass
+// (root id, number within the root) for rt_photon_order.hip to sum per texel in that order — or, with
+// RT_OPT_PHOTON_ORDER = 0, added to the atlas with float atomics (texels equal to rounding only).
 template <bool HAS_JULIA, bool STATS>
 __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(const DevScene sc, const DevPhotonJob job) {
     Counters n;
@@ -1291,6 +1292,9 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
     unsigned depth = 0;
     bool need = true;
     WaveIds wave_ids = wave_ids_begin(gid, job.n_waves, job.static_blocks);
+    unsigned long long root_id = 0;      // of the tree this lane walks, and the number of its deposits so far:
+    unsigned root_deposits = 0;          // together the position of a deposit in the reference's sequential pass
+    unsigned long long dep_next = 0, dep_end = 0;   // records this wave has reserved (wave-uniform)
     for (;;) {
         // refill idle lanes with new roots
         while (__any(need)) {
@@ -1300,6 +1304,8 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                 need = false;
                 if (got) {
                     id += job.root_base;
+                    root_id = id;
+                    root_deposits = 0;
                     const unsigned hue = static_cast<unsigned>(id % job.hues);
                     unsigned long long q = id / job.hues;
                     const unsigned ti = static_cast<unsigned>(q % job.n_theta);
@@ -1327,6 +1333,9 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
 
         const bool mine = L.state == S_QUERY;
         query_objects<STATS>(sc, L, mine, n);
+        bool deposit = false;
+        unsigned deposit_texel = 0;
+        float deposit_rad[4] = {0, 0, 0, 0};
         if (mine) {
             bump<STATS>(n, C_PHOTON_SEGMENTS);
             if (HAS_JULIA) {
@@ -1349,12 +1358,9 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                     const int slot = T.object_photon_slot[L.best_obj];
                     if (depth > 0 && slot >= 0) {
                         bump<STATS>(n, C_PHOTON_DEPOSITS);
-                        const unsigned texel = photon_texel(L.best.ph, sc.photon_size);
-                        float* t = reinterpret_cast<float*>(sc.photon_atlas + static_cast<size_t>(slot) * sc.photon_size * sc.photon_size + texel);
-                        atomicAdd(t + 0, rad[0]);
-                        atomicAdd(t + 1, rad[1]);
-                        atomicAdd(t + 2, rad[2]);
-                        atomicAdd(t + 3, rad[3]);
+                        deposit = true;
+                        deposit_texel = static_cast<unsigned>(slot) * sc.photon_size * sc.photon_size + photon_texel(L.best.ph, sc.photon_size);
+                        for (int c = 0; c < 4; c++) deposit_rad[c] = rad[c];
                     }
                 } else if (depth + 1 <= sc.max_bounces) {
                     const float cosv = clampf(dot(L.qd, L.best.normal), -1.0f, 1.0f);
@@ -1394,6 +1400,42 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                     L.state = S_IDLE;
                     need = true;
                 }
+            }
+        }
+        // Object::addPhoton (src/objects.cpp:244-256), with the wave converged again
+        const unsigned long long dep_mask = __ballot(deposit);
+        if (dep_mask != 0) {
+            bool add_now = deposit;
+            if (job.dep_keys != nullptr) {
+                const unsigned lane = threadIdx.x & 63u;
+                const unsigned cnt = static_cast<unsigned>(__popcll(dep_mask));
+                if (dep_next + cnt > dep_end) {   // the rest of the old chunk stays unused (its keys sort last)
+                    unsigned long long base = 0;
+                    if (lane == static_cast<unsigned>(__ffsll(static_cast<long long>(dep_mask)) - 1)) base = atomicAdd(job.dep_words, static_cast<unsigned long long>(kDepositChunk));
+                    base = __shfl(base, __ffsll(static_cast<long long>(dep_mask)) - 1);
+                    dep_next = base;
+                    dep_end = base + kDepositChunk;
+                }
+                const unsigned long long slot_index = dep_next + static_cast<unsigned>(__popcll(dep_mask & ((1ull << lane) - 1ull)));
+                dep_next += cnt;
+                if (deposit) {
+                    if (slot_index < job.dep_capacity) {
+                        job.dep_keys[slot_index] = (static_cast<unsigned long long>(deposit_texel) << (job.dep_root_bits + job.dep_seq_bits)) |
+                                                   (root_id << job.dep_seq_bits) | root_deposits;
+                        job.dep_vals[slot_index] = make_float4(deposit_rad[0], deposit_rad[1], deposit_rad[2], deposit_rad[3]);
+                        add_now = false;
+                    } else {
+                        atomicAdd(job.dep_words + 1, 1ull);   // buffer full: this deposit is added out of order (host grows the buffer)
+                    }
+                    root_deposits++;
+                }
+            }
+            if (add_now) {
+                float* t = reinterpret_cast<float*>(sc.photon_atlas + deposit_texel);
+                atomicAdd(t + 0, deposit_rad[0]);
+                atomicAdd(t + 1, deposit_rad[1]);
+                atomicAdd(t + 2, deposit_rad[2]);
+                atomicAdd(t + 3, deposit_rad[3]);
             }
         }
     }

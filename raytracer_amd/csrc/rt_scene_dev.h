@@ -182,7 +182,20 @@ struct DevPhotonJob {
     uint32_t static_blocks;         // as in DevJob
     uint32_t n_waves;
     uint64_t dyn_base;
+    // Reference deposit order (RT_OPT_PHOTON_ORDER = 1): deposits are RECORDED, not added — key =
+    // (texel of the atlas, root id, number of the deposit within its root), value = the radiance — then
+    // sorted and summed per texel in key order, which is the order of the reference's sequential pass
+    // (rt_photon_order.hip).  dep_keys == NULL: float atomics straight into the atlas.
+    unsigned long long* dep_keys;   // [dep_capacity], preset to ~0 (sorts last)
+    float4* dep_vals;               // [dep_capacity]
+    unsigned long long* dep_words;  // [0] next free record, [1] deposits that found the buffer full
+    uint32_t dep_capacity;
+    uint32_t dep_seq_bits;          // key = texel << (dep_root_bits + dep_seq_bits) | root << dep_seq_bits | seq
+    uint32_t dep_root_bits;
+    uint32_t dep_pad;
 };
+constexpr uint32_t kDepositChunk = 64;      // records a wave reserves per atomic
+constexpr uint32_t kDepositLongRun = 32;    // deposits into one texel from which a wave sums them (rt_photon_order.hip)
 
 // Shape of trace_julia_kernel's workgroup (rt_kernels.hip), shared with the launch code
 #ifndef RT_JULIA_WAVES

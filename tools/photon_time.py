@@ -1,10 +1,16 @@
-import sys, os, time
-sys.path.insert(0, os.getcwd())
-from raytracer_amd import capi
+"""Developer probe (GPU box): time of the photon pass, reference deposit order against float atomics."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracer_amd import capi  # noqa: E402
+
 ctx = capi.Context(0)
 for path, t in (("scenes/examples3/103_caustic_animation.xml", 0.5), ("scenes/examples2/9_caustic.xml", 0.0)):
-    sc = capi.Scene(path, t); ctx.upload(sc)
-    ts = []
-    for i in range(6):
-        ts.append(ctx.photon_generate().kernel_ms)
-    print(os.path.basename(path), "photon ms", ["%.3f" % x for x in ts])
+    sc = capi.Scene(os.path.join(ROOT, path), t)
+    for ordered in (1, 0):
+        ctx.set_option(capi.RT_OPT_PHOTON_ORDER, ordered)
+        ctx.upload(sc)
+        ts = [ctx.photon_generate().kernel_ms for _ in range(6)]
+        print(os.path.basename(path), "ordered" if ordered else "atomics", "photon ms", ["%.3f" % x for x in ts], flush=True)
