@@ -578,6 +578,61 @@ def test_two_julia_sets_through_the_job_queues(tmp_path):
 
 # ---- every example scene the reference ships -----------------------------------------------------------
 
+def _scene_xml(tmp_path, name, camera, lights, surfaces, extra=""):
+    xml = tmp_path / (name + ".xml")
+    xml.write_text('''<scene output_file="%s.png"><background_color r="0.25" g="0.5" b="0.75"/>%s
+  <camera><position x="0" y="0" z="1"/><lookat x="0" y="0" z="-2.5"/><up x="0" y="1" z="0"/><horizontal_fov angle="45"/>%s</camera>
+  <lights>%s</lights><surfaces>%s</surfaces></scene>''' % (name, extra, camera, lights, surfaces))
+    return str(xml)
+
+
+GLASS_SPHERE = '''<sphere radius="1.0"><position x="0" y="0" z="-3"/><material_solid><color r="0.2" g="0.6" b="0.3"/>
+  <phong ka="0.3" kd="0.9" ks="1.0" exponent="50"/><reflectance r="0.5"/><transmittance t="0.5"/><refraction iof="1.5"/></material_solid></sphere>'''
+WALL = '''<mesh name="%s"><material_solid><color r="0.7" g="0.7" b="0.7"/><phong ka="0.3" kd="0.9" ks="0.2" exponent="10"/>
+  <reflectance r="0"/><transmittance t="0"/><refraction iof="0"/></material_solid>
+  <transform><translate x="0" y="0" z="-6"/><scale x="8" y="8" z="1"/></transform></mesh>'''
+POINT = '<ambient_light><color r="1" g="1" b="1"/></ambient_light><point_light><color r="0.8" g="0.8" b="0.8"/><position x="2" y="3" z="1"/></point_light>'
+PARALLEL = '<ambient_light><color r="1" g="1" b="1"/></ambient_light><parallel_light><color r="0.8" g="0.8" b="0.8"/><direction x="-1" y="-1" z="-1"/></parallel_light>'
+
+
+@pytest.mark.parametrize("case", ["empty", "one_pixel", "no_bounces", "no_lights", "photons_without_point_light", "wide_thin", "photons_one_receiver"])
+def test_degenerate_scenes(hip_ctx, tmp_path, case):
+    """Edge cases of the path: nothing to hit, a single pixel, recursion cut at the first hit, no lights at all,
+    a photon pass with nothing to emit, an image thinner than a tile, a photon pass into a single receiver."""
+    wall = WALL % scene_path("examples/plane_small.obj")
+    res = lambda w, h, b=4, ss=1: '<resolution horizontal="%d" vertical="%d"/><max_bounces n="%d"/><supersampling subpixels_peraxis="%d"/>' % (w, h, b, ss)
+    path = {
+        "empty": lambda: _scene_xml(tmp_path, case, res(37, 21), "", ""),
+        "one_pixel": lambda: _scene_xml(tmp_path, case, res(1, 1, 4, 3), POINT, GLASS_SPHERE + wall),
+        "no_bounces": lambda: _scene_xml(tmp_path, case, res(64, 48, 0), POINT, GLASS_SPHERE + wall),
+        "no_lights": lambda: _scene_xml(tmp_path, case, res(64, 48), "", GLASS_SPHERE + wall),
+        "photons_without_point_light": lambda: _scene_xml(tmp_path, case, res(64, 48), PARALLEL, GLASS_SPHERE + wall,
+                                                           '<caustic steps="50" texture_size="16" factor="0.1"/>'),
+        "wide_thin": lambda: _scene_xml(tmp_path, case, res(515, 3), POINT, GLASS_SPHERE + wall),
+        "photons_one_receiver": lambda: _scene_xml(tmp_path, case, res(96, 64), POINT, GLASS_SPHERE + wall,
+                                                    '<caustic steps="1000" texture_size="8" factor="0.05"/>'),
+    }[case]()
+    sc = capi.Scene(path, 0.0)
+    hip_ctx.upload(sc)
+    hip_ctx.set_option(capi.RT_OPT_COLLECT_STATS, 1)
+    pst = hip_ctx.photon_generate()
+    img, st = hip_ctx.render()
+    hip_ctx.set_option(capi.RT_OPT_COLLECT_STATS, 0)
+    ph = oracle_lib.Photons(sc) if sc.desc.photon_steps > 0 else None
+    ref, ost = oracle_lib.render(sc, ph, threads=8)
+    assert img.shape == ref.shape
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), case
+    assert (st.primary_rays, st.secondary_rays, st.shadow_rays) == (ost.primary_rays, ost.secondary_rays, ost.shadow_rays)
+    if ph is not None:
+        assert (pst.photon_segments, pst.photon_deposits) == (ph.stats.photon_segments, ph.stats.photon_deposits)
+        for o in range(sc.desc.n_objects):
+            assert np.array_equal(hip_ctx.photon_download(o).view(np.uint32), ph.texture(o).view(np.uint32)), (case, o)
+    if case == "empty":
+        assert np.all(img == np.array([0.25, 0.5, 0.75, 1.0], dtype=np.float32))
+    if case == "photons_one_receiver":
+        assert pst.photon_deposits > 32 * 64      # many deposits per texel: the long-run path of rt_photon_order.hip
+
+
 ALL_SCENES = [
     ("examples/example2.xml", 0.0), ("examples/example3.xml", 0.0), ("examples/example4.xml", 0.0),
     ("examples/example5.xml", 0.0), ("examples/example6.xml", 0.0), ("examples/example7.xml", 0.0),
