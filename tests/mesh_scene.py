@@ -132,3 +132,78 @@ def write_two_julia_scene(tmp_path, width=120, height=90):
       <transform><translate x="0.9" y="0.1" z="-0.8"/><rotateY theta="40"/><scale x="1.2" y="0.9" z="1.0"/></transform></julia>
   </surfaces></scene>''' % (width, height, plane))
     return str(xml)
+
+
+def write_random_scene(tmp_path, seed):
+    """A seeded random scene over the whole grammar of the path: spheres under random transform chains,
+    meshes, solid and textured materials with every combination of the reflect / transmit / complex index /
+    dispersion switches, 0-3 lights of both kinds, ragged image sizes, supersampling, recursion depths
+    0-5, now and then a photon pass or a Julia set.  For the GPU-against-oracle sweep."""
+    import random
+    rnd = random.Random(seed)
+    ex = os.path.join(ROOT, "scenes", "examples")
+    u = rnd.uniform
+
+    def material():
+        textured = rnd.random() < 0.3
+        refl = rnd.choice(["0", "0", "0.5", "1.0"])
+        trans = rnd.choice(["0", "0", "0.7"])
+        iof = rnd.choice(["0", "1.3", "1.5168", "2.3"]) if (refl != "0" or trans != "0") else rnd.choice(["0", "1.5"])
+        ec = rnd.choice(["", "", ' ec="1.0"', ' ec="9.7525e-9"'])
+        disp = ' disp="-0.2"' if rnd.random() < 0.12 and iof != "0" else ""
+        phong = '<phong ka="%.2f" kd="%.2f" ks="%.2f" exponent="%d"/>' % (u(0, 0.5), u(0.2, 1.0), u(0, 1.0), rnd.choice([1, 10, 50, 200, 1000]))
+        tail = '%s<reflectance r="%s"/><transmittance t="%s"/><refraction iof="%s"%s%s/>' % (phong, refl, trans, iof, ec, disp)
+        if textured:
+            return '<material_textured><texture name="%s"/>%s</material_textured>' % (os.path.join(ex, rnd.choice(["mramor6x6.png", "rainbow.png"])), tail)
+        return '<material_solid><color r="%.2f" g="%.2f" b="%.2f"/>%s</material_solid>' % (u(0, 1), u(0, 1), u(0, 1), tail)
+
+    def transform(spread):
+        ops = ['<translate x="%.3f" y="%.3f" z="%.3f"/>' % (u(-spread, spread), u(-1, 1.5), u(-spread, spread))]
+        for _ in range(rnd.randrange(0, 4)):
+            k = rnd.randrange(0, 4)
+            if k == 3:
+                ops.append('<scale x="%.3f" y="%.3f" z="%.3f"/>' % (u(0.4, 1.8), u(0.4, 1.8), u(0.4, 1.8)))
+            else:
+                ops.append('<rotate%s theta="%.1f"/>' % ("XYZ"[k], u(-180, 180)))
+        return "<transform>%s</transform>" % "".join(ops)
+
+    with_photons = seed % 4 == 1
+    diffuse = ('<material_solid><color r="0.6" g="0.6" b="0.6"/><phong ka="0.3" kd="0.8" ks="0.3" exponent="20"/><reflectance r="0"/>'
+               '<transmittance t="0"/><refraction iof="0"/></material_solid>')
+    glass = ('<material_solid><color r="0.2" g="0.3" b="0.5"/><phong ka="0.1" kd="0.2" ks="1.0" exponent="200"/><reflectance r="0.8"/>'
+             '<transmittance t="0.8"/><refraction iof="1.5168" ec="9.7525e-9"%s/></material_solid>' % (' disp="-0.2"' if seed % 8 == 1 else ""))
+    surfaces = ['<mesh name="%s">%s<transform><translate x="0" y="-1.5" z="0"/><rotateX theta="-90"/><scale x="8" y="8" z="1"/></transform></mesh>'
+                % (os.path.join(ex, "plane_small.obj"), diffuse if with_photons else material())]
+    if with_photons:   # something that focuses light onto the diffuse floor
+        surfaces.append('<sphere radius="0.8"><position x="0" y="0" z="0"/>%s<transform><translate x="%.2f" y="0.2" z="%.2f"/><scale x="1.0" y="%.2f" z="1.0"/></transform></sphere>'
+                        % (glass, u(-1, 1), u(-1, 1), u(0.6, 1.4)))
+    for _ in range(rnd.randrange(1, 6)):
+        surfaces.append('<sphere radius="%.3f"><position x="%.2f" y="%.2f" z="%.2f"/>%s%s</sphere>'
+                        % (u(0.3, 1.0), u(-0.5, 0.5), u(-0.5, 0.5), u(-0.5, 0.5), material(), transform(2.5)))
+    for _ in range(rnd.randrange(0, 3)):
+        surfaces.append('<mesh name="%s">%s%s</mesh>' % (os.path.join(ex, rnd.choice(["box.obj", "cone.obj"])), material(), transform(2.5)))
+    julia = seed % 6 == 5
+    if julia:
+        surfaces.append('<julia scale="1.2" cr="%.3f" ca="%.3f" cb="%.3f" cc="%.3f" cutplane="%.2f"><position x="0" y="0.3" z="0"/>%s</julia>'
+                        % (u(-0.4, 0.1), u(-0.5, 0.6), u(-0.3, 0.4), u(-0.2, 0.5), u(-0.2, 0.2), material()))
+    rnd.shuffle(surfaces)
+    lights = ['<ambient_light><color r="%.2f" g="%.2f" b="%.2f"/></ambient_light>' % (u(0.5, 1), u(0.5, 1), u(0.5, 1))]
+    if with_photons:
+        lights.append('<point_light><color r="0.8" g="0.8" b="0.8"/><position x="%.2f" y="4" z="%.2f"/></point_light>' % (u(-1, 1), u(-1, 1)))
+    for _ in range(rnd.randrange(0, 4)):
+        if rnd.random() < 0.6:
+            lights.append('<point_light><color r="%.2f" g="%.2f" b="%.2f"/><position x="%.2f" y="%.2f" z="%.2f"/></point_light>'
+                          % (u(0.2, 0.9), u(0.2, 0.9), u(0.2, 0.9), u(-4, 4), u(1, 5), u(-2, 4)))
+        else:
+            lights.append('<parallel_light><color r="%.2f" g="%.2f" b="%.2f"/><direction x="%.2f" y="%.2f" z="%.2f"/></parallel_light>'
+                          % (u(0.2, 0.6), u(0.2, 0.6), u(0.2, 0.6), u(-1, 1), u(-1, -0.2), u(-1, 1)))
+    w, h = (rnd.choice([48, 57]), rnd.choice([32, 41])) if julia else (rnd.choice([64, 83, 96]), rnd.choice([48, 57, 71]))
+    caustic = '<caustic steps="%d" texture_size="%d" factor="0.3"/>' % (rnd.choice([90, 150]), rnd.choice([8, 24])) if with_photons else ""
+    xml = tmp_path / ("random_%d.xml" % seed)
+    xml.write_text('''<scene output_file="random_%d.png"><background_color r="%.2f" g="%.2f" b="%.2f"/>%s
+  <camera><position x="%.2f" y="%.2f" z="%.2f"/><lookat x="%.2f" y="%.2f" z="0"/><up x="0" y="1" z="0"/><horizontal_fov angle="%d"/>
+    <resolution horizontal="%d" vertical="%d"/><max_bounces n="%d"/><supersampling subpixels_peraxis="%d"/></camera>
+  <lights>%s</lights>
+  <surfaces>%s</surfaces></scene>''' % (seed, u(0, 0.5), u(0, 0.5), u(0, 0.5), caustic, u(-2, 2), u(0.2, 2.5), u(4, 6), u(-0.5, 0.5), u(-0.5, 0.5),
+                                         rnd.choice([30, 45, 60]), w, h, rnd.randrange(2, 6) if with_photons else rnd.randrange(0, 6), rnd.choice([1, 1, 2]), "".join(lights), "\n    ".join(surfaces)))
+    return str(xml)
