@@ -824,6 +824,9 @@ constexpr int kJuliaTracerLanes = (kJuliaWaves - kJuliaMarcherWaves) * 64;   // 
 constexpr unsigned kJuliaQueueCap = kJuliaTracerLanes <= 512 ? 512u : 1024u;    // an owner has at most one job in flight
 static_assert(sizeof(float) * (11 + 11) * kJuliaTracerLanes + 16 * kJuliaQueueCap + 64 <= kJuliaStaticLdsBytes, "kJuliaStaticLdsBytes");
 static_assert(kJuliaQueueCap >= kJuliaTracerLanes && (kJuliaQueueCap & (kJuliaQueueCap - 1)) == 0, "ring size");
+#ifndef RT_JULIA_FUSE_QUERY
+#define RT_JULIA_FUSE_QUERY 1
+#endif
 #ifndef RT_JULIA_STEP_DIVISOR
 #define RT_JULIA_STEP_DIVISOR 2
 #endif
@@ -1160,30 +1163,9 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
         if (n_query + n_resolve == 0) {
             if (n_wait == 0) break;
         } else if (n_wait == 0 || n_query + n_resolve >= RT_JULIA_TRACER_MIN_READY || lds_load(&sh.hungry) != 0u || wait_rounds > 64u) {
-            phase = n_query >= n_resolve ? S_QUERY : S_RESOLVE;
+            phase = RT_JULIA_FUSE_QUERY ? (n_resolve > 0 ? S_RESOLVE : S_QUERY) : (n_query >= n_resolve ? S_QUERY : S_RESOLVE);
         }
-        if (phase == S_QUERY) {
-            const bool mine = L.state == S_QUERY;
-            if (STATS) {
-                if ((threadIdx.x & 63) == 0) n.v[D_QUERY_PHASES]++;
-                if (mine) n.v[D_QUERY_LANES]++;
-            }
-            query_objects<STATS>(sc, L, mine, n);
-            if (mine) {
-                L.state = S_RESOLVE;
-                if (L.qactive) {
-                    for (unsigned k = 0; k < sc.n_julias; k++) {
-                        bump<STATS>(n, C_JULIA_QUERIES);
-                        if (julia_enter(sc.julias[k], L.qo, L.qd, L.jp, L.jd)) {
-                            L.jidx = k;
-                            L.state = S_WAIT;
-                            push = true;
-                            break;
-                        }
-                    }
-                }
-            }
-        } else if (phase == S_RESOLVE) {
+        if (phase == S_RESOLVE) {
             const bool mine = L.state == S_RESOLVE;
             if (STATS) {
                 if ((threadIdx.x & 63) == 0) n.v[D_RESOLVE_PHASES]++;
@@ -1210,6 +1192,30 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
                     } else if (start_sample(sc, job, id, L)) {
                         need = false;
                         fresh = false;
+                    }
+                }
+            }
+        }
+        // A resolve leaves its lanes with their next query: it runs in the same pass (RT_JULIA_FUSE_QUERY), so a
+        // ray costs the tracer one pass, not two, and reaches the marchers a pass earlier.
+        if (phase == S_QUERY || (RT_JULIA_FUSE_QUERY && phase == S_RESOLVE && __any(L.state == S_QUERY))) {
+            const bool mine = L.state == S_QUERY;
+            if (STATS) {
+                if ((threadIdx.x & 63) == 0) n.v[D_QUERY_PHASES]++;
+                if (mine) n.v[D_QUERY_LANES]++;
+            }
+            query_objects<STATS>(sc, L, mine, n);
+            if (mine) {
+                L.state = S_RESOLVE;
+                if (L.qactive) {
+                    for (unsigned k = 0; k < sc.n_julias; k++) {
+                        bump<STATS>(n, C_JULIA_QUERIES);
+                        if (julia_enter(sc.julias[k], L.qo, L.qd, L.jp, L.jd)) {
+                            L.jidx = k;
+                            L.state = S_WAIT;
+                            push = true;
+                            break;
+                        }
                     }
                 }
             }
