@@ -1340,7 +1340,7 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
         const bool mine = L.state == S_QUERY;
         query_objects<STATS>(sc, L, mine, n);
         bool deposit = false;
-        unsigned deposit_texel = 0;
+        unsigned long long deposit_texel = 0;   // texel of the whole atlas (receivers x size^2 can exceed 2^32)
         float deposit_rad[4] = {0, 0, 0, 0};
         if (mine) {
             bump<STATS>(n, C_PHOTON_SEGMENTS);
@@ -1365,7 +1365,7 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                     if (depth > 0 && slot >= 0) {
                         bump<STATS>(n, C_PHOTON_DEPOSITS);
                         deposit = true;
-                        deposit_texel = static_cast<unsigned>(slot) * sc.photon_size * sc.photon_size + photon_texel(L.best.ph, sc.photon_size);
+                        deposit_texel = static_cast<unsigned long long>(slot) * sc.photon_size * sc.photon_size + photon_texel(L.best.ph, sc.photon_size);
                         for (int c = 0; c < 4; c++) deposit_rad[c] = rad[c];
                     }
                 } else if (depth + 1 <= sc.max_bounces) {
@@ -1426,7 +1426,7 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                 dep_next += cnt;
                 if (deposit) {
                     if (slot_index < job.dep_capacity) {
-                        job.dep_keys[slot_index] = (static_cast<unsigned long long>(deposit_texel) << (job.dep_root_bits + job.dep_seq_bits)) |
+                        job.dep_keys[slot_index] = (deposit_texel << (job.dep_root_bits + job.dep_seq_bits)) |
                                                    (root_id << job.dep_seq_bits) | root_deposits;
                         job.dep_vals[slot_index] = make_float4(deposit_rad[0], deposit_rad[1], deposit_rad[2], deposit_rad[3]);
                         add_now = false;
