@@ -224,7 +224,8 @@ int rt_fetch_stats(rt_ctx* ctx, rt_stats* out);
  * src/photonmap.cpp:32-56: point lights in scene order, then phi, theta, hue) into this context's
  * zeroed photon textures.  The caller then SUMS the textures of all parts — rt_photon_atlas_device
  * gives the device buffer (all receivers' textures, contiguous floats) for an in-place all-reduce —
- * before any rt_render.  part 0 of 1 is rt_photon_generate_device.  The reference's pass is
+ * before any rt_render.  The pointer stays valid until the next rt_scene_upload or rt_destroy on this
+ * context (an upload reallocates and clears the textures).  part 0 of 1 is rt_photon_generate_device.  The reference's pass is
  * single-threaded; the sum of the parts equals its textures up to the order of the float additions
  * (within a slice the deposits keep the reference's order, RT_OPT_PHOTON_ORDER). */
 int rt_photon_generate_part_device(rt_ctx* ctx, void* hip_stream, uint32_t part, uint32_t n_parts);
