@@ -1312,12 +1312,25 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                     id += job.root_base;
                     root_id = id;
                     root_deposits = 0;
-                    const unsigned hue = static_cast<unsigned>(id % job.hues);
-                    unsigned long long q = id / job.hues;
-                    const unsigned ti = static_cast<unsigned>(q % job.n_theta);
-                    q /= job.n_theta;
-                    const unsigned pi = static_cast<unsigned>(q % job.n_phi);
-                    const unsigned li = static_cast<unsigned>(q / job.n_phi);
+                    // (light, phi, theta, hue) of root `id`; 64-bit division costs some 150 instructions a piece, and the
+                    // wave pays for the decode in every round in which a single lane starts a root
+                    unsigned hue, ti, pi, li;
+                    if ((job.root_base + job.n_roots) >> 32 == 0) {
+                        const unsigned i32 = static_cast<unsigned>(id);
+                        hue = i32 % job.hues;
+                        unsigned q = i32 / job.hues;
+                        ti = q % job.n_theta;
+                        q /= job.n_theta;
+                        pi = q % job.n_phi;
+                        li = q / job.n_phi;
+                    } else {
+                        hue = static_cast<unsigned>(id % job.hues);
+                        unsigned long long q = id / job.hues;
+                        ti = static_cast<unsigned>(q % job.n_theta);
+                        q /= job.n_theta;
+                        pi = static_cast<unsigned>(q % job.n_phi);
+                        li = static_cast<unsigned>(q / job.n_phi);
+                    }
                     const DevLight& light = T.lights[job.point_lights[li]];
                     const float st = job.sin_theta[ti], ct = job.cos_theta[ti], sp_ = job.sin_phi[pi], cp = job.cos_phi[pi];
                     const V3 dir = normalized(v3(st * cp, st * sp_, ct));
