@@ -478,8 +478,28 @@ CameraFrame camera_frame(const rt_camera& cam) {
     return f;
 }
 
-// One pixel: src/raytracer.cpp:55-112.  Depth of field draws are replaced by zeros (lens_size == 0
-// in every pinned config; with lens_size != 0 the reference is not reproducible).
+// The two lens-jitter draws of a sample (src/raytracer.cpp:86-89).  The reference takes them from a
+// std::minstd_rand seeded by std::random_device per worker thread with rows handed out dynamically:
+// its pictures with lens_size != 0 are not reproducible run to run, so there is nothing
+// to restate bit for bit.  The product path draws from a counter-based hash of (pixel, sub-pixel,
+// seed) instead (rt_kernels.hip: start_sample); the oracle uses the same function so that everything
+// around the draw stays comparable bit for bit.  (lens_size == 0 in every pinned config: the draws
+// are multiplied by zero there.)
+uint32_t g_dof_seed = 0;
+uint32_t lens_hash(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+V2 lens_draws(const rt_camera& cam, uint32_t x, uint32_t y, uint32_t sub) {
+    const uint32_t h1 = lens_hash((y * cam.width + x) * 64u + sub + g_dof_seed * 0x9e3779b9u), h2 = lens_hash(h1 ^ 0x68bc21ebu);
+    return {static_cast<float>(h1 >> 8) * (2.0f / 16777216.0f) - 1.0f, static_cast<float>(h2 >> 8) * (2.0f / 16777216.0f) - 1.0f};
+}
+
+// One pixel: src/raytracer.cpp:55-112.
 Col render_pixel(Tracer& tr, const CameraFrame& f, uint32_t x, uint32_t y) {
     const rt_scene_desc& sc = tr.sc;
     const rt_camera& cam = sc.camera;
@@ -493,7 +513,8 @@ Col render_pixel(Tracer& tr, const CameraFrame& f, uint32_t x, uint32_t y) {
             const V2 target_disp = {sub_disp.x * f.pixel_size.x, sub_disp.y * f.pixel_size.y};
             const V3 on_plane = {ray_x + target_disp.x, ray_y + target_disp.y, -1.0f};
             const V3 on_focus = xform_point(cam.camera_to_world, mul(on_plane, cam.focus_distance));
-            const V2 lens = {(sub_disp.x + 0.0f * (1.0f / nsub)) * cam.lens_size, (sub_disp.y + 0.0f * (1.0f / nsub)) * cam.lens_size};
+            const V2 draw = lens_draws(cam, x, y, sy * nsub + sx);
+            const V2 lens = {(sub_disp.x + draw.x * (1.0f / nsub)) * cam.lens_size, (sub_disp.y + draw.y * (1.0f / nsub)) * cam.lens_size};
             V3 origin = xform_point(cam.camera_to_world, {0.0f, 0.0f, 0.0f});
             origin = {origin.x + lens.x, origin.y + lens.y, origin.z};
             const Ray ray = make_ray(origin, sub(on_focus, origin));
@@ -674,6 +695,9 @@ void oracle_photon_set(oracle_photons* p, uint32_t object_index, const float* rg
 }
 
 void oracle_photon_free(oracle_photons* p) { delete p; }
+
+// Seed of the lens-jitter hash (RT_OPT_DOF_SEED of the product path); default 0
+void oracle_set_dof_seed(uint32_t seed) { g_dof_seed = seed; }
 
 // texture_size^2 RGBA floats of object `object_index`; zeros if it never received a photon
 void oracle_photon_get(const oracle_photons* p, uint32_t object_index, float* rgba_out) {

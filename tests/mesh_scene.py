@@ -199,11 +199,14 @@ def write_random_scene(tmp_path, seed):
                           % (u(0.2, 0.6), u(0.2, 0.6), u(0.2, 0.6), u(-1, 1), u(-1, -0.2), u(-1, 1)))
     w, h = (rnd.choice([48, 57]), rnd.choice([32, 41])) if julia else (rnd.choice([64, 83, 96]), rnd.choice([48, 57, 71]))
     caustic = '<caustic steps="%d" texture_size="%d" factor="0.3"/>' % (rnd.choice([90, 150]), rnd.choice([8, 24])) if with_photons else ""
+    # depth of field: the lens jitter is a counter-based hash here and in the oracle (the reference's is not reproducible)
+    dof = '<dof x="%.2f" y="%.2f" z="%.2f" lenssize="%.2f"/>' % (u(-0.5, 0.5), u(-0.5, 0.5), u(-1, 1), u(0.05, 0.3)) if seed % 7 == 3 else ""
     xml = tmp_path / ("random_%d.xml" % seed)
     xml.write_text('''<scene output_file="random_%d.png"><background_color r="%.2f" g="%.2f" b="%.2f"/>%s
   <camera><position x="%.2f" y="%.2f" z="%.2f"/><lookat x="%.2f" y="%.2f" z="0"/><up x="0" y="1" z="0"/><horizontal_fov angle="%d"/>
-    <resolution horizontal="%d" vertical="%d"/><max_bounces n="%d"/><supersampling subpixels_peraxis="%d"/></camera>
+    <resolution horizontal="%d" vertical="%d"/><max_bounces n="%d"/><supersampling subpixels_peraxis="%d"/>%s</camera>
   <lights>%s</lights>
   <surfaces>%s</surfaces></scene>''' % (seed, u(0, 0.5), u(0, 0.5), u(0, 0.5), caustic, u(-2, 2), u(0.2, 2.5), u(4, 6), u(-0.5, 0.5), u(-0.5, 0.5),
-                                         rnd.choice([30, 45, 60]), w, h, rnd.randrange(2, 6) if with_photons else rnd.randrange(0, 6), rnd.choice([1, 1, 2]), "".join(lights), "\n    ".join(surfaces)))
+                                         rnd.choice([30, 45, 60]), w, h, rnd.randrange(2, 6) if with_photons else rnd.randrange(0, 6),
+                                         2 if dof else rnd.choice([1, 1, 2]), dof, "".join(lights), "\n    ".join(surfaces)))
     return str(xml)

@@ -22,6 +22,7 @@ def lib():
         l.oracle_photon_generate_part.argtypes = [C.POINTER(capi.SceneDesc), C.c_uint32, C.c_uint32, C.POINTER(capi.Stats)]
         l.oracle_photon_set.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         l.oracle_photon_free.argtypes = [C.c_void_p]
+        l.oracle_set_dof_seed.argtypes = [C.c_uint32]
         l.oracle_photon_get.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         l.oracle_render.argtypes = [C.POINTER(capi.SceneDesc), C.c_void_p, C.c_int, C.c_void_p, C.POINTER(capi.Stats)]
         l.oracle_render_rows.argtypes = [C.POINTER(capi.SceneDesc), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -64,6 +65,11 @@ class Photons:
         if self._h:
             lib().oracle_photon_free(self._h)
             self._h = None
+
+
+def set_dof_seed(seed):
+    """Seed of the lens-jitter hash (RT_OPT_DOF_SEED of the product path); process-wide, default 0."""
+    lib().oracle_set_dof_seed(seed)
 
 
 def render(scene, photons=None, threads=8, rows=None):
