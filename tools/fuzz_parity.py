@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): the random-scene parity sweep of tests/test_gpu_parity.py over many more seeds.
-tools/fuzz_parity.py FIRST LAST  -> prints the seeds whose picture or photon textures differ from the oracle's."""
+tools/fuzz_parity.py FIRST LAST [BVH_MIN_TRIANGLES]  -> prints the seeds whose picture or photon textures differ from the
+oracle's.  BVH_MIN_TRIANGLES = 1 sends every triangle run through the BVH traversal instead of the culled scan."""
 import os
 import pathlib
 import sys
@@ -20,6 +21,8 @@ def main():
     first, last = int(sys.argv[1]), int(sys.argv[2])
     tmp = pathlib.Path(tempfile.mkdtemp())
     ctx = capi.Context(0)
+    if len(sys.argv) > 3:
+        ctx.set_option(capi.RT_OPT_BVH_MIN_TRIANGLES, int(sys.argv[3]))
     bad = []
     for seed in range(first, last):
         sc = capi.Scene(mesh_scene.write_random_scene(tmp, seed), 0.0)
