@@ -196,7 +196,7 @@ enum {
                                    bit-identical to the reference's.  0: float atomics, textures equal to rounding (fastest).
                                    rt_photon_generate_device on a scene whose deposits outgrow the record buffer adds the
                                    surplus with atomics and sizes the buffer for the next pass; rt_photon_generate reruns. */
-    RT_OPT_PHOTON_RECORDS = 5   /* capacity of that record buffer in deposits; 0 (default) = an eighth of the root photons,
+    RT_OPT_PHOTON_RECORDS = 5   /* capacity of that record buffer in deposits; 0 (default) = a sixteenth of the root photons,
                                    at least 262144; grows by itself as described above */
 };
 int rt_set_option(rt_ctx* ctx, int option, int64_t value);
@@ -229,6 +229,13 @@ int rt_fetch_stats(rt_ctx* ctx, rt_stats* out);
  * single-threaded; the sum of the parts equals its textures up to the order of the float additions
  * (within a slice the deposits keep the reference's order, RT_OPT_PHOTON_ORDER). */
 int rt_photon_generate_part_device(rt_ctx* ctx, void* hip_stream, uint32_t part, uint32_t n_parts);
+
+/* Waits for the last photon pass enqueued on this context and reports whether ALL of its deposits were summed in
+ * the reference's order (*ordered_out = 1), or not (0: RT_OPT_PHOTON_ORDER is off, the key did not fit 64 bits, or
+ * the pass outgrew the record buffer and its surplus was added with atomics — the buffer has then been resized and
+ * enqueueing the pass again gives the ordered result).  For callers of the asynchronous entry points that want the
+ * guarantee rt_photon_generate gives by itself.  No counterpart in the reference (its pass is sequential). */
+int rt_photon_ordered(rt_ctx* ctx, int* ordered_out);
 int rt_photon_atlas_device(rt_ctx* ctx, void** d_atlas_out, uint64_t* n_floats_out);
 
 /* Test hook: copies the photon texture of scene object `object_index` (texture_size^2 RGBA floats;

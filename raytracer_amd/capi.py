@@ -263,6 +263,7 @@ def hip_lib():
         lib.rt_photon_generate_device.argtypes = [C.c_void_p, C.c_void_p]
         lib.rt_photon_generate_part_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         lib.rt_photon_atlas_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        lib.rt_photon_ordered.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         lib.rt_fetch_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         lib.rt_photon_download.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         lib.rt_mul_add_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint64, C.c_void_p]
@@ -284,6 +285,7 @@ class Context:
         if rc != 0:
             raise RtError("rt_create failed (%d): %s" % (rc, self._lib.rt_last_error(None).decode()))
         self.scene = None
+        self.ordered_photons = True      # RT_OPT_PHOTON_ORDER as last set through set_option
 
     def _check(self, rc, what):
         if rc != 0:
@@ -295,6 +297,8 @@ class Context:
 
     def set_option(self, option, value):
         self._check(self._lib.rt_set_option(self._ctx, option, value), "rt_set_option")
+        if option == RT_OPT_PHOTON_ORDER:
+            self.ordered_photons = bool(value)
 
     def photon_generate(self):
         st = Stats()
@@ -327,6 +331,12 @@ class Context:
     def photon_generate_part_device(self, part, n_parts, stream=None):
         self._check(self._lib.rt_photon_generate_part_device(self._ctx, C.c_void_p(stream or 0), part, n_parts),
                     "rt_photon_generate_part_device")
+
+    def photon_ordered(self):
+        """Waits for the last photon pass; True if all of its deposits were summed in the reference's order."""
+        flag = C.c_int()
+        self._check(self._lib.rt_photon_ordered(self._ctx, C.byref(flag)), "rt_photon_ordered")
+        return bool(flag.value)
 
     def photon_atlas_device(self):
         """(device pointer, number of floats) of all photon textures of the uploaded scene; (0, 0) without receivers."""

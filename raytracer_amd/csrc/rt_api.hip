@@ -85,6 +85,7 @@ struct rt_ctx {
     hipEvent_t ev_dep = nullptr;
     bool dep_check_pending = false;
     bool dep_last_pass_ordered = false;
+    bool dep_last_pass_overflowed = false;   // sticky until the next pass is enqueued
     // per-call scratch, grown on demand and kept
     Buffer samples, stack, out_staging, kat_a, kat_b, kat_c, kat_d;
     unsigned long long* d_queue = nullptr;      // [0] = queue head
@@ -279,6 +280,7 @@ unsigned bit_width(unsigned long long v) {
 bool deposit_overflow_seen(rt_ctx* ctx) {
     if (!ctx->dep_check_pending || hipEventQuery(ctx->ev_dep) != hipSuccess) return false;
     ctx->dep_check_pending = false;
+    ctx->dep_last_pass_overflowed = ctx->h_dep_words[1] != 0;
     if (ctx->h_dep_words[1] == 0) return false;
     const unsigned long long wanted = ctx->h_dep_words[0] + ctx->h_dep_words[0] / 4;
     ctx->dep_capacity = static_cast<uint32_t>(std::min<unsigned long long>((wanted + 65535ull) & ~65535ull, 1ull << 31));
@@ -288,8 +290,8 @@ bool deposit_overflow_seen(rt_ctx* ctx) {
 int deposit_buffers(rt_ctx* ctx, unsigned long long all_roots, unsigned key_bits) {
     (void)deposit_overflow_seen(ctx);
     if (ctx->dep_capacity == 0) {
-        // C5: 8.0 M roots leave 0.37 M deposits; a wave reserves records kDepositChunk at a time
-        const unsigned long long guess = std::max<unsigned long long>(1ull << 18, all_roots / 8);
+        // C5: 8.0 M roots leave 0.37 M deposits (+ 0.05 M slots that stay unused: a wave reserves records kDepositChunk at a time)
+        const unsigned long long guess = std::max<unsigned long long>(1ull << 18, all_roots / 16);
         ctx->dep_capacity = static_cast<uint32_t>(std::min<unsigned long long>((guess + 65535ull) & ~65535ull, 1ull << 31));
     }
     const size_t n = ctx->dep_capacity;
@@ -356,6 +358,7 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
         const unsigned key_bits = texel_bits + root_bits + seq_bits;
         const bool ordered = ctx->photon_order && key_bits <= 64;
         ctx->dep_last_pass_ordered = ordered;
+        ctx->dep_last_pass_overflowed = false;
         if (ordered) {
             if ((rc = deposit_buffers(ctx, all_roots, key_bits)) != RT_OK) return rc;
             job.dep_keys = static_cast<unsigned long long*>(ctx->dep_keys.ptr);
@@ -925,6 +928,18 @@ int rt_photon_generate_part_device(rt_ctx* ctx, void* hip_stream, uint32_t part,
     if (n_parts == 0 || part >= n_parts) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_photon_generate_part_device: part must be < n_parts");
     RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return photon_enqueue(ctx, static_cast<hipStream_t>(hip_stream), part, n_parts);
+}
+
+int rt_photon_ordered(rt_ctx* ctx, int* ordered_out) {
+    if (ctx == nullptr || ordered_out == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    *ordered_out = 0;
+    if (!ctx->dep_last_pass_ordered) return RT_OK;
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->dep_check_pending) RT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_dep));
+    const bool overflowed = deposit_overflow_seen(ctx) || ctx->dep_last_pass_overflowed;
+    ctx->dep_last_pass_overflowed = overflowed;
+    *ordered_out = overflowed ? 0 : 1;
+    return RT_OK;
 }
 
 int rt_photon_atlas_device(rt_ctx* ctx, void** d_atlas_out, uint64_t* n_floats_out) {

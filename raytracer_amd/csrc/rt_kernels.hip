@@ -1430,10 +1430,11 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                 const unsigned cnt = static_cast<unsigned>(__popcll(dep_mask));
                 if (dep_next + cnt > dep_end) {   // the rest of the old chunk stays unused (its keys sort last)
                     unsigned long long base = 0;
-                    if (lane == static_cast<unsigned>(__ffsll(static_cast<long long>(dep_mask)) - 1)) base = atomicAdd(job.dep_words, static_cast<unsigned long long>(kDepositChunk));
+                    const unsigned reserve = cnt > kDepositChunk ? cnt : kDepositChunk;
+                    if (lane == static_cast<unsigned>(__ffsll(static_cast<long long>(dep_mask)) - 1)) base = atomicAdd(job.dep_words, static_cast<unsigned long long>(reserve));
                     base = __shfl(base, __ffsll(static_cast<long long>(dep_mask)) - 1);
                     dep_next = base;
-                    dep_end = base + kDepositChunk;
+                    dep_end = base + reserve;
                 }
                 const unsigned long long slot_index = dep_next + static_cast<unsigned>(__popcll(dep_mask & ((1ull << lane) - 1ull)));
                 dep_next += cnt;

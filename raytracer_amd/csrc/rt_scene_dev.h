@@ -194,7 +194,7 @@ struct DevPhotonJob {
     uint32_t dep_root_bits;
     uint32_t dep_pad;
 };
-constexpr uint32_t kDepositChunk = 64;      // records a wave reserves per atomic
+constexpr uint32_t kDepositChunk = 32;      // records a wave reserves per atomic
 constexpr uint32_t kDepositLongRun = 32;    // deposits into one texel from which a wave sums them (rt_photon_order.hip)
 
 // Shape of trace_julia_kernel's workgroup (rt_kernels.hip), shared with the launch code

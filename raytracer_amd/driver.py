@@ -49,12 +49,20 @@ class HipRenderer:
         torch.cuda.set_device(self.device)
         self.ctx = capi.Context(device_index)
 
+    def _photon_pass(self, enqueue):
+        """Enqueues a photon pass; if it outgrew the record buffer of the ordered sum (the library has resized it
+        by then) the pass runs once more, so that the textures are the reference's bit for bit."""
+        stream = torch.cuda.current_stream().cuda_stream
+        enqueue(stream)
+        if self.ctx.ordered_photons and not self.ctx.photon_ordered():
+            enqueue(stream)
+
     def photon_pass(self, scene, part, n_parts):
         """Uploads the scene and emits slice `part` of `n_parts` of its photon pass.  Returns the photon
         textures as a flat float tensor ALIASING the context's device buffer (None without receivers):
         the caller sums it over the ranks in place, then calls render(..., photons_ready=True)."""
         self.ctx.upload(scene)
-        self.ctx.photon_generate_part_device(part, n_parts, torch.cuda.current_stream().cuda_stream)
+        self._photon_pass(lambda stream: self.ctx.photon_generate_part_device(part, n_parts, stream))
         ptr, n = self.ctx.photon_atlas_device()
         if n == 0:
             return None
@@ -65,7 +73,7 @@ class HipRenderer:
         if not photons_ready:      # (an upload clears the photon textures)
             self.ctx.upload(scene)
             if scene.desc.photon_steps > 0:
-                self.ctx.photon_generate_device(stream)
+                self._photon_pass(self.ctx.photon_generate_device)
         n = self.ctx.pixel_count(bands)
         out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         if n:

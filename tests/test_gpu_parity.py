@@ -341,13 +341,25 @@ def test_photon_record_buffer_grows_when_a_scene_outgrows_it(hip_ctx):
     other.upload(sc)
     for attempt in range(2):
         other.photon_generate_device()
-        torch.cuda.synchronize()
+        assert other.photon_ordered() == (attempt == 1)       # reported, and the buffer has the right size afterwards
         for o in range(sc.desc.n_objects):
             a, b = other.photon_download(o), ph.texture(o)
             if attempt == 0:
                 assert np.allclose(a, b, rtol=2e-6, atol=0), o
             else:
                 assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), o
+    # the driver's renderer asks and repeats the pass by itself
+    from raytracer_amd import driver
+    r = driver.HipRenderer(0)
+    r.ctx.set_option(capi.RT_OPT_PHOTON_RECORDS, 4096)
+    img = r.render(sc).cpu().numpy()
+    ref, _ = oracle_lib.render(sc, ph, threads=16)
+    assert np.array_equal(img.reshape(ref.shape).view(np.uint32), ref.view(np.uint32))
+    hip_ctx.set_option(capi.RT_OPT_PHOTON_ORDER, 0)
+    hip_ctx.upload(sc)
+    hip_ctx.photon_generate_device()
+    assert not hip_ctx.photon_ordered()
+    hip_ctx.set_option(capi.RT_OPT_PHOTON_ORDER, 1)
 
 
 # ---- partitions, accumulation, quantiser -------------------------------------------------------------
