@@ -735,8 +735,12 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
                     c.hi[a] = std::fmax(c.hi[a], hi + grow);
                 }
             }
+            // distance slack of the cull (rt_kernels.hip: query_bvh explains): 1e-4 of the box's size here, 1e-4 of
+            // the distance in the kernel
+            c.slack = 1e-4f * ((c.hi[0] - c.lo[0]) + (c.hi[1] - c.lo[1]) + (c.hi[2] - c.lo[2]));
             if (!bounded) {
                 for (int a = 0; a < 3; a++) { c.lo[a] = -INFINITY; c.hi[a] = INFINITY; }
+                c.slack = 0.0f;
             }
             chunks.push_back(c);
         }

@@ -197,7 +197,13 @@ RT_DEV void query_bvh(const DevScene& sc, Lane& L, unsigned act, unsigned bvh_ro
         const float z0 = (a.z - L.qo.z) * inv.z, z1 = (b.z - L.qo.z) * inv.z;
         const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
         const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-        const bool overlap = !(tnear > tfar * 1.0000004f) && !(tfar < 0.0f) && !(tnear > L.qmax);
+        // The distance the triangle test computes (src/objects.cpp:56-81) and the slab distances computed here
+        // are different roundings of the same number: a box is flat when its triangles lie in an axis plane,
+        // and the test may then put the hit a few ulp in front of the box.  The scan accepts t == maximum (an
+        // exact tie goes to the later object), so a box is skipped only when it lies beyond the maximum by
+        // more than that noise can be (1e-4 of the distance and of the box: ~10^3 ulp, no measurable cost).
+        const float t_slack = 1e-4f * ((b.x - a.x) + (b.y - a.y) + (b.z - a.z));
+        const bool overlap = !(tnear > tfar * 1.0000004f) && !(tfar < -t_slack) && !(tnear * 0.9999f - t_slack > L.qmax);
         const unsigned ia = __float_as_uint(a.w), ib = __float_as_uint(b.w);
         if (overlap) {
             if (ib == kBvhLeaf) {
@@ -262,7 +268,9 @@ RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, Counters& 
                     const float z0 = (cb->lo[2] - L.qo.z) * inv.z, z1 = (cb->hi[2] - L.qo.z) * inv.z;
                     const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
                     const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-                    const bool overlap = !(tnear > tfar * 1.0000004f) && !(tfar < 0.0f) && !(tnear > L.qmax);
+                    // (t_slack: see query_bvh — the triangle test's distance and the slab's are different roundings)
+                    const float t_slack = cb->slack;
+                    const bool overlap = !(tnear > tfar * 1.0000004f) && !(tfar < -t_slack) && !(tnear * 0.9999f - t_slack > L.qmax);
                     if (!__any(act != 0u && overlap)) {
                         if (act != 0u) bump<STATS>(n, C_TRIANGLE_TESTS, count - i < RT_TRI_GROUP ? count - i : RT_TRI_GROUP);
                         continue;

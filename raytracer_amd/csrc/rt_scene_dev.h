@@ -88,7 +88,7 @@ struct DevLight {
 constexpr uint32_t kTriChunk = 4;
 struct DevTriChunk {
     float lo[3];
-    float pad0;
+    float slack;             // distance slack of the cull: 1e-4 of the box's extents
     float hi[3];
     float pad1;
 };

@@ -186,6 +186,13 @@ def write_random_scene(tmp_path, seed):
     if julia:
         surfaces.append('<julia scale="1.2" cr="%.3f" ca="%.3f" cb="%.3f" cc="%.3f" cutplane="%.2f"><position x="0" y="0.3" z="0"/>%s</julia>'
                         % (u(-0.4, 0.1), u(-0.5, 0.6), u(-0.3, 0.4), u(-0.2, 0.5), u(-0.2, 0.2), material()))
+    if seed % 3 == 0:
+        # the same surface twice with another material: every hit on it is an exact tie, decided by scene order
+        # (an object.intersect(ray, max) at t == max is a hit, so the later object wins: src/raytracer.cpp:128-141)
+        import re
+        twin = rnd.choice(surfaces)
+        other = material()
+        surfaces.append(re.sub(r"<material_(solid|textured)>.*?</material_(solid|textured)>", lambda _m: other, twin, count=1, flags=re.S))
     rnd.shuffle(surfaces)
     lights = ['<ambient_light><color r="%.2f" g="%.2f" b="%.2f"/></ambient_light>' % (u(0.5, 1), u(0.5, 1), u(0.5, 1))]
     if with_photons:
