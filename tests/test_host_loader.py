@@ -130,3 +130,39 @@ def test_png_writer_is_byte_identical_to_the_reference(tmp_path):
     out = str(tmp_path / "again.png")
     capi.png_write(out, img)
     assert open(out, "rb").read() == open(golden_path("c1_example1.png"), "rb").read()
+
+
+REF_HARNESS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ref_harness")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_HARNESS), reason="reference build absent (GPU box)")
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scenes_flatten_like_the_reference(tmp_path, seed):
+    """The loader against the reference's own parser (oracle/_ref/ref_harness fingerprint, the reference's
+    Scene::load flattened word for word) on seeded random scenes: transform chains, every material switch,
+    lights, Julia sets, depth of field, caustic settings — and keyframed attributes at a random time."""
+    import random
+    import re
+    import subprocess
+    import mesh_scene
+    path = mesh_scene.write_random_scene(tmp_path, seed)
+    rnd = random.Random(1000 + seed)
+    text = open(path).read()
+    if seed % 2:
+        # animate some numeric attributes with the keyframe grammar (value;value(ease,time);...)
+        def animate(m):
+            if rnd.random() < 0.25:
+                v = float(m.group(2))
+                ease = rnd.choice(["l", "i", "o", "b"])
+                return '%s="%s;%.3f(%s,%.2f);%.3f"' % (m.group(1), m.group(2), v + rnd.uniform(-1, 1), ease, rnd.uniform(0.2, 0.6), v + rnd.uniform(-1, 1))
+            return m.group(0)
+        text = re.sub(r'\b(x|y|z|theta|radius)="(-?\d+\.\d+)"', animate, text)
+        open(path, "w").write(text)
+    t = float(np.float32(rnd.choice([0.0, 0.25, 0.61, 1.0])))
+    out = str(tmp_path / "ref.fp.bin")
+    subprocess.check_call([REF_HARNESS, "fingerprint", path, repr(t), out], stdout=subprocess.DEVNULL)
+    ref = np.fromfile(out, dtype=np.uint32)
+    mine = capi.Scene(path, t).fingerprint()
+    assert len(ref) == len(mine), (seed, len(ref), len(mine))
+    bad = np.nonzero(ref != mine)[0]
+    assert len(bad) == 0, (seed, t, bad[:8].tolist())
