@@ -166,7 +166,8 @@ def write_random_scene(tmp_path, seed):
         for _ in range(rnd.randrange(0, 4)):
             k = rnd.randrange(0, 4)
             if k == 3:
-                ops.append('<scale x="%.3f" y="%.3f" z="%.3f"/>' % (u(0.4, 1.8), u(0.4, 1.8), u(0.4, 1.8)))
+                flip = (lambda: rnd.choice([-1.0, 1.0])) if seed % 11 == 4 else (lambda: 1.0)   # mirrored objects now and then
+                ops.append('<scale x="%.3f" y="%.3f" z="%.3f"/>' % (flip() * u(0.4, 1.8), flip() * u(0.4, 1.8), flip() * u(0.4, 1.8)))
             else:
                 ops.append('<rotate%s theta="%.1f"/>' % ("XYZ"[k], u(-180, 180)))
         return "<transform>%s</transform>" % "".join(ops)
