@@ -689,6 +689,24 @@ def test_random_scenes_vs_oracle(hip_ctx, tmp_path, seed):
     assert np.array_equal(bvh.view(np.uint32), ref.view(np.uint32)), (seed, "bvh")
 
 
+REF_EXECUTABLE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "raytracer_ostrict")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_EXECUTABLE), reason="oracle/_ref not built")
+@pytest.mark.parametrize("seed", [0, 1, 2, 5, 9, 12, 22, 78])
+def test_cli_writes_the_file_the_reference_executable_writes(tmp_path, seed):
+    """End to end, as a user swaps the programs: the drop-in CLI (loader, kernels, quantiser, PNG writer) and the
+    reference's own executable (built from its sources in the build container; it travels as oracle/_ref) on the
+    same random scene file — the two PNG files must be the same bytes.  tools/fuzz_cli.py is the long version."""
+    import subprocess
+    import mesh_scene
+    scene = mesh_scene.write_random_scene(tmp_path, seed)
+    a, b = str(tmp_path / "reference.png"), str(tmp_path / "hip.png")
+    subprocess.check_call([REF_EXECUTABLE, scene, a], stdout=subprocess.DEVNULL)
+    subprocess.check_call([os.path.join(os.path.dirname(REF_EXECUTABLE), "..", "..", "raytracer_amd", "rt_amd"), scene, b], stdout=subprocess.DEVNULL)
+    assert open(a, "rb").read() == open(b, "rb").read()
+
+
 ALL_SCENES = [
     ("examples/example2.xml", 0.0), ("examples/example3.xml", 0.0), ("examples/example4.xml", 0.0),
     ("examples/example5.xml", 0.0), ("examples/example6.xml", 0.0), ("examples/example7.xml", 0.0),
