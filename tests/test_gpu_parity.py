@@ -614,7 +614,13 @@ POINT = '<ambient_light><color r="1" g="1" b="1"/></ambient_light><point_light><
 PARALLEL = '<ambient_light><color r="1" g="1" b="1"/></ambient_light><parallel_light><color r="0.8" g="0.8" b="0.8"/><direction x="-1" y="-1" z="-1"/></parallel_light>'
 
 
-@pytest.mark.parametrize("case", ["empty", "one_pixel", "no_bounces", "no_lights", "photons_without_point_light", "wide_thin", "photons_one_receiver"])
+MIRROR = '''<mesh name="%s"><material_solid><color r="0.9" g="0.9" b="0.9"/><phong ka="0.1" kd="0.3" ks="0.5" exponent="30"/>
+  <reflectance r="1.0"/><transmittance t="0"/><refraction iof="2.5" ec="3.0"/></material_solid>
+  <transform><translate x="0" y="0" z="%s"/>%s<scale x="400" y="400" z="1"/></transform></mesh>'''
+
+
+@pytest.mark.parametrize("case", ["empty", "one_pixel", "no_bounces", "no_lights", "photons_without_point_light", "wide_thin", "photons_one_receiver",
+                                  "deep_mirrors"])
 def test_degenerate_scenes(hip_ctx, tmp_path, case):
     """Edge cases of the path: nothing to hit, a single pixel, recursion cut at the first hit, no lights at all,
     a photon pass with nothing to emit, an image thinner than a tile, a photon pass into a single receiver."""
@@ -628,6 +634,10 @@ def test_degenerate_scenes(hip_ctx, tmp_path, case):
         "photons_without_point_light": lambda: _scene_xml(tmp_path, case, res(64, 48), PARALLEL, GLASS_SPHERE + wall,
                                                            '<caustic steps="50" texture_size="16" factor="0.1"/>'),
         "wide_thin": lambda: _scene_xml(tmp_path, case, res(515, 3), POINT, GLASS_SPHERE + wall),
+        # two facing mirrors: reflection chains as deep as the recursion limit allows (64 is the ABI's maximum)
+        "deep_mirrors": lambda: _scene_xml(tmp_path, case, res(96, 64, 64), POINT, GLASS_SPHERE.replace('t="0.5"', 't="0"')
+                                           + MIRROR % (scene_path("examples/plane_small.obj"), "-7", "")
+                                           + MIRROR % (scene_path("examples/plane_small.obj"), "3", '<rotateY theta="180"/>')),
         "photons_one_receiver": lambda: _scene_xml(tmp_path, case, res(96, 64), POINT, GLASS_SPHERE + wall,
                                                     '<caustic steps="1000" texture_size="8" factor="0.05"/>'),
     }[case]()
