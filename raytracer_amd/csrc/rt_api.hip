@@ -80,12 +80,13 @@ struct rt_ctx {
     Buffer dep_keys, dep_vals, dep_sorted_keys, dep_sorted_index, dep_long_runs, dep_temp;
     uint32_t dep_capacity = 0;         // records; 0 = choose from the number of roots
     size_t dep_temp_bytes = 0;
-    unsigned long long* d_dep_words = nullptr;   // [0] records reserved, [1] deposits that found the buffer full, [2] long runs
+    unsigned long long* d_dep_words = nullptr;   // [0] records reserved, [1] deposits that found the buffer full, [2] long runs, [3] deposits beyond a root's key field
     unsigned long long* h_dep_words = nullptr;   // pinned copy, written by the stream after every ordered pass
     hipEvent_t ev_dep = nullptr;
     bool dep_check_pending = false;
     bool dep_last_pass_ordered = false;
     bool dep_last_pass_overflowed = false;   // sticky until the next pass is enqueued
+    bool dep_key_too_narrow = false;         // a root made more deposits than the order key has bits for
     // per-call scratch, grown on demand and kept
     Buffer samples, stack, out_staging, kat_a, kat_b, kat_c, kat_d;
     unsigned long long* d_queue = nullptr;      // [0] = queue head
@@ -280,7 +281,8 @@ unsigned bit_width(unsigned long long v) {
 bool deposit_overflow_seen(rt_ctx* ctx) {
     if (!ctx->dep_check_pending || hipEventQuery(ctx->ev_dep) != hipSuccess) return false;
     ctx->dep_check_pending = false;
-    ctx->dep_last_pass_overflowed = ctx->h_dep_words[1] != 0;
+    ctx->dep_last_pass_overflowed = ctx->h_dep_words[1] != 0 || ctx->h_dep_words[3] != 0;
+    ctx->dep_key_too_narrow = ctx->h_dep_words[3] != 0;
     if (ctx->h_dep_words[1] == 0) return false;
     const unsigned long long wanted = ctx->h_dep_words[0] + ctx->h_dep_words[0] / 4;
     ctx->dep_capacity = static_cast<uint32_t>(std::min<unsigned long long>((wanted + 65535ull) & ~65535ull, 1ull << 31));
@@ -354,9 +356,13 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
         RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 2 * sizeof(unsigned long long), stream));
         // reference deposit order: record, sort, sum (rt_photon_order.hip) when the key fits 64 bits
         const unsigned long long n_texels = static_cast<unsigned long long>(ctx->n_slots) * ctx->dev.photon_size * ctx->dev.photon_size;
-        const unsigned texel_bits = bit_width(n_texels), root_bits = bit_width(all_roots), seq_bits = ctx->dev.max_bounces + 2;
+        // a root deposits at most once per leaf of its tree, 2^(max_bounces+1) in theory; when the key has no room for
+        // that many the pass still runs ordered and reports the (never yet seen) root that outgrew its field
+        const unsigned texel_bits = bit_width(n_texels), root_bits = bit_width(all_roots);
+        const unsigned seq_room = texel_bits + root_bits < 64 ? 64 - texel_bits - root_bits : 0;
+        const unsigned seq_bits = std::min<unsigned>(ctx->dev.max_bounces + 2, std::min<unsigned>(seq_room, 31));
         const unsigned key_bits = texel_bits + root_bits + seq_bits;
-        const bool ordered = ctx->photon_order && key_bits <= 64;
+        const bool ordered = ctx->photon_order && seq_bits >= std::min<unsigned>(ctx->dev.max_bounces + 2, 10);
         ctx->dep_last_pass_ordered = ordered;
         ctx->dep_last_pass_overflowed = false;
         if (ordered) {

@@ -1447,7 +1447,9 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                 const unsigned long long slot_index = dep_next + static_cast<unsigned>(__popcll(dep_mask & ((1ull << lane) - 1ull)));
                 dep_next += cnt;
                 if (deposit) {
-                    if (slot_index < job.dep_capacity) {
+                    if (root_deposits >> job.dep_seq_bits != 0u) {
+                        atomicAdd(job.dep_words + 3, 1ull);   // more deposits from one root than the key has room for
+                    } else if (slot_index < job.dep_capacity) {
                         job.dep_keys[slot_index] = (deposit_texel << (job.dep_root_bits + job.dep_seq_bits)) |
                                                    (root_id << job.dep_seq_bits) | root_deposits;
                         job.dep_vals[slot_index] = make_float4(deposit_rad[0], deposit_rad[1], deposit_rad[2], deposit_rad[3]);

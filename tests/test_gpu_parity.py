@@ -620,7 +620,7 @@ MIRROR = '''<mesh name="%s"><material_solid><color r="0.9" g="0.9" b="0.9"/><pho
 
 
 @pytest.mark.parametrize("case", ["empty", "one_pixel", "no_bounces", "no_lights", "photons_without_point_light", "wide_thin", "photons_one_receiver",
-                                  "deep_mirrors"])
+                                  "deep_mirrors", "photons_deep"])
 def test_degenerate_scenes(hip_ctx, tmp_path, case):
     """Edge cases of the path: nothing to hit, a single pixel, recursion cut at the first hit, no lights at all,
     a photon pass with nothing to emit, an image thinner than a tile, a photon pass into a single receiver."""
@@ -638,6 +638,11 @@ def test_degenerate_scenes(hip_ctx, tmp_path, case):
         "deep_mirrors": lambda: _scene_xml(tmp_path, case, res(96, 64, 64), POINT, GLASS_SPHERE.replace('t="0.5"', 't="0"')
                                            + MIRROR % (scene_path("examples/plane_small.obj"), "-7", "")
                                            + MIRROR % (scene_path("examples/plane_small.obj"), "3", '<rotateY theta="180"/>')),
+        # photons bouncing between the mirrors for up to 40 segments before they land on the diffuse sphere
+        "photons_deep": lambda: _scene_xml(tmp_path, case, res(96, 64, 40), POINT, GLASS_SPHERE.replace('t="0.5"', 't="0"').replace('r="0.5"', 'r="0"').replace('iof="1.5"', 'iof="0"')
+                                           + MIRROR % (scene_path("examples/plane_small.obj"), "-7", "")
+                                           + MIRROR % (scene_path("examples/plane_small.obj"), "3", '<rotateY theta="180"/>'),
+                                           '<caustic steps="200" texture_size="16" factor="0.2"/>'),
         "photons_one_receiver": lambda: _scene_xml(tmp_path, case, res(96, 64), POINT, GLASS_SPHERE + wall,
                                                     '<caustic steps="1000" texture_size="8" factor="0.05"/>'),
     }[case]()
