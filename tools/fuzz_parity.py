@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): the random-scene parity sweep of tests/test_gpu_parity.py over many more seeds.
-tools/fuzz_parity.py FIRST LAST [BVH_MIN_TRIANGLES]  -> prints the seeds whose picture or photon textures differ from the
+tools/fuzz_parity.py FIRST LAST [BVH_MIN_TRIANGLES [WIDTHxHEIGHT]]  -> prints the seeds whose picture or photon textures differ from the
 oracle's.  BVH_MIN_TRIANGLES = 1 sends every triangle run through the BVH traversal instead of the culled scan."""
 import os
 import pathlib
@@ -26,6 +26,12 @@ def main():
     bad = []
     for seed in range(first, last):
         sc = capi.Scene(mesh_scene.write_random_scene(tmp, seed), 0.0)
+        if len(sys.argv) > 4:       # larger pictures: more tiles than waves, so the dynamic part of the work distribution runs
+            if sc.desc.n_julias > 0:
+                continue            # (the CPU oracle needs minutes for a large Julia picture)
+            w, h = (int(v) for v in sys.argv[4].split("x"))
+            sc.set_camera(w, h, 0)
+            print("seed", seed, flush=True)
         ctx.upload(sc)
         ctx.photon_generate()
         img, _ = ctx.render()
