@@ -17,8 +17,13 @@ raytracer_amd/libraytracer_host.so: $(HOST_SRCS) $(HOST_HDRS)
 	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRCS) -lz
 
 hip: raytracer_amd/librt_hip.so
-raytracer_amd/librt_hip.so: $(wildcard raytracer_amd/csrc/*.hip) $(wildcard raytracer_amd/csrc/*.h) include/rt_hip.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(wildcard raytracer_amd/csrc/*.hip)
+HIP_SRCS = $(wildcard raytracer_amd/csrc/*.hip)
+HIP_OBJS = $(patsubst raytracer_amd/csrc/%.hip,build/%.o,$(HIP_SRCS))
+build/%.o: raytracer_amd/csrc/%.hip $(wildcard raytracer_amd/csrc/*.h) include/rt_hip.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+raytracer_amd/librt_hip.so: $(HIP_OBJS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_OBJS)
 
 cli: raytracer_amd/rt_amd
 raytracer_amd/rt_amd: $(wildcard raytracer_amd/host/*.cpp) $(HOST_HDRS) raytracer_amd/librt_hip.so
@@ -31,5 +36,6 @@ oracle:
 
 clean:
 	rm -f raytracer_amd/*.so raytracer_amd/rt_amd
+	rm -rf build
 	$(MAKE) -C oracle clean
 .PHONY: all host hip cli oracle clean

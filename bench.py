@@ -237,6 +237,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    ctx.launch_status()      # raises if the Julia kernel's watchdog abandoned the last launch
 
     if rank == 0:
         value = rays_per_step * world * args.steps / elapsed

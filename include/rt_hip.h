@@ -196,8 +196,10 @@ enum {
                                    bit-identical to the reference's.  0: float atomics, textures equal to rounding (fastest).
                                    rt_photon_generate_device on a scene whose deposits outgrow the record buffer adds the
                                    surplus with atomics and sizes the buffer for the next pass; rt_photon_generate reruns. */
-    RT_OPT_PHOTON_RECORDS = 5   /* capacity of that record buffer in deposits; 0 (default) = a sixteenth of the root photons,
+    RT_OPT_PHOTON_RECORDS = 5,  /* capacity of that record buffer in deposits; 0 (default) = a sixteenth of the root photons,
                                    at least 262144; grows by itself as described above */
+    RT_OPT_DEBUG_FORCE_ABORT = 6 /* test hook, 0/1: the Julia kernel's first workgroup raises its watchdog flag at once, as a wave
+                                   stuck on the job queues would: the launch is then reported as abandoned (RT_ERR_HIP) */
 };
 int rt_set_option(rt_ctx* ctx, int option, int64_t value);
 
@@ -218,6 +220,11 @@ int rt_render(rt_ctx* ctx, const rt_bands* bands_or_null, float* rgba_out, rt_st
 int rt_render_device(rt_ctx* ctx, const rt_bands* bands_or_null, void* d_rgba_out, void* hip_stream);
 int rt_photon_generate_device(rt_ctx* ctx, void* hip_stream);
 int rt_fetch_stats(rt_ctx* ctx, rt_stats* out);
+/* Waits for the last rt_render_device launch on this context and returns RT_ERR_HIP if the Julia kernel's watchdog
+ * abandoned it (a wave waited too long on the job queues; the picture is incomplete), else RT_OK.  rt_render and
+ * rt_fetch_stats make the same check themselves.  Callers of rt_render_device call this before they use the picture.
+ * Replaces: nothing in the reference (its trace cannot stall; errors there are exceptions, src/main.cpp:202-205). */
+int rt_launch_status(rt_ctx* ctx);
 
 /* One photon pass split over several GPUs: emits only slice `part` of `n_parts` equal
  * contiguous slices of the root-photon sequence of PhotonMapper::generate (reference

@@ -18,6 +18,7 @@ RT_OBJ_SPHERE, RT_OBJ_TRIANGLE, RT_OBJ_JULIA = 0, 1, 2
 RT_LIGHT_PARALLEL, RT_LIGHT_POINT = 0, 1
 RT_HUE_INT_ABS, RT_HUE_FLOAT_ABS = 0, 1
 RT_OPT_COLLECT_STATS, RT_OPT_BVH_MIN_TRIANGLES, RT_OPT_DOF_SEED, RT_OPT_PHOTON_ORDER, RT_OPT_PHOTON_RECORDS = 1, 2, 3, 4, 5
+RT_OPT_DEBUG_FORCE_ABORT = 6
 RT_DEFAULT_BVH_MIN_TRIANGLES = 256
 FLT_MAX = float(np.finfo(np.float32).max)
 
@@ -265,6 +266,7 @@ def hip_lib():
         lib.rt_photon_atlas_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         lib.rt_photon_ordered.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         lib.rt_fetch_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        lib.rt_launch_status.argtypes = [C.c_void_p]
         lib.rt_photon_download.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         lib.rt_mul_add_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint64, C.c_void_p]
         lib.rt_quantize_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint64, C.c_void_p]
@@ -348,6 +350,10 @@ class Context:
         st = Stats()
         self._check(self._lib.rt_fetch_stats(self._ctx, C.byref(st)), "rt_fetch_stats")
         return st
+
+    def launch_status(self):
+        """Waits for the last render_device launch; raises if the Julia kernel's watchdog abandoned it."""
+        self._check(self._lib.rt_launch_status(self._ctx), "rt_launch_status")
 
     def photon_download(self, object_index):
         size = self.scene.desc.photon_texture_size

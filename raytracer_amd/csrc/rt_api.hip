@@ -89,7 +89,10 @@ struct rt_ctx {
     bool dep_key_too_narrow = false;         // a root made more deposits than the order key has bits for
     // per-call scratch, grown on demand and kept
     Buffer samples, stack, out_staging, kat_a, kat_b, kat_c, kat_d;
-    unsigned long long* d_queue = nullptr;      // [0] = queue head
+    unsigned long long* d_queue = nullptr;      // [0] = queue head, [1] = watchdog flag of trace_julia_kernel (sticky until read)
+    unsigned long long* h_status = nullptr;     // pinned copy of d_queue[1], written by the stream after every render launch
+    bool status_pending = false;                // a render launch whose watchdog word has not been looked at yet
+    bool debug_force_abort = false;             // RT_OPT_DEBUG_FORCE_ABORT
     unsigned long long* d_counters = nullptr;   // rt_stats words
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool events_pending = false;
@@ -245,7 +248,9 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     job.stack = static_cast<float*>(ctx->stack.ptr);
     job.queue_head = ctx->d_queue;
     job.counters = ctx->d_counters;
-    RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 2 * sizeof(unsigned long long), stream));   // [0] queue head, [1] watchdog flag
+    job.debug_abort = ctx->debug_force_abort ? 1u : 0u;
+    // [0] queue head: cleared per launch.  [1] watchdog flag: sticky, cleared only once the host has seen it (launch_status)
+    RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), stream));
     RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long), stream));
     RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
     if (julia) {
@@ -261,9 +266,23 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
         hipLaunchKernelGGL(sum_samples_kernel, dim3(g), dim3(256), 0, stream, job.samples, job.out, job.n_pixels, job.samples_per_pixel, ctx->dev.inv_samples);
         RT_HIP_TRY(ctx, hipGetLastError());
     }
+    if (julia) RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_queue + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream));
     ctx->events_pending = true;
+    ctx->status_pending = julia;
     return RT_OK;
+}
+
+// Waits for the last render launch and reports a launch that trace_julia_kernel's watchdog abandoned (a wave waited
+// too long on the job queues: the picture is incomplete).  The device flag stays set until it has been seen here.
+int launch_status(rt_ctx* ctx) {
+    if (!ctx->status_pending) return RT_OK;
+    RT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_end));
+    ctx->status_pending = false;
+    if (*ctx->h_status == 0) return RT_OK;
+    *ctx->h_status = 0;
+    RT_HIP_TRY(ctx, hipMemset(ctx->d_queue + 1, 0, sizeof(unsigned long long)));
+    return fail(ctx, RT_ERR_HIP, "trace_julia_kernel: a wave waited too long on the job queues and the launch was abandoned");
 }
 
 unsigned bit_width(unsigned long long v) {
@@ -399,13 +418,12 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
 }
 
 int read_stats(rt_ctx* ctx, rt_stats* out) {
+    const int status = launch_status(ctx);   // before the early return: a caller without stats must hear of an abandoned launch too
+    if (status != RT_OK) return status;
     if (out == nullptr) return RT_OK;
     std::memset(out, 0, sizeof *out);
     unsigned long long c[C_COUNT];
     RT_HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
-    unsigned long long q[2] = {0, 0};
-    RT_HIP_TRY(ctx, hipMemcpy(q, ctx->d_queue, sizeof q, hipMemcpyDeviceToHost));
-    if (q[1] != 0) return fail(ctx, RT_ERR_HIP, "trace_julia_kernel: a wave waited too long on the job queues and the launch was abandoned");
     out->primary_rays = c[C_PRIMARY];
     out->secondary_rays = c[C_SECONDARY];
     out->shadow_rays = c[C_SHADOW];
@@ -474,6 +492,7 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
         hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), C_COUNT * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&ctx->d_dep_words), 4 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->h_dep_words), 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&ctx->ev_dep) != hipSuccess ||
         hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) {
         delete ctx;
@@ -481,6 +500,7 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
     }
     (void)hipMemset(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long));
     (void)hipMemset(ctx->d_queue, 0, 256);   // [0] queue head, [1] watchdog flag of trace_julia_kernel
+    *ctx->h_status = 0;
     *out_ctx = ctx;
     return RT_OK;
 }
@@ -496,6 +516,7 @@ void rt_destroy(rt_ctx* ctx) {
     }
     if (ctx->d_dep_words) (void)hipFree(ctx->d_dep_words);
     if (ctx->h_dep_words) (void)hipHostFree(ctx->h_dep_words);
+    if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->ev_dep) (void)hipEventDestroy(ctx->ev_dep);
     if (ctx->d_point_lights) (void)hipFree(ctx->d_point_lights);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
@@ -516,6 +537,7 @@ int rt_set_option(rt_ctx* ctx, int option, int64_t value) {
             if (value < 0 || value > (1ll << 31)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_PHOTON_RECORDS out of range");
             ctx->dep_capacity = static_cast<uint32_t>((value + 63) & ~63ll);
             return RT_OK;
+        case RT_OPT_DEBUG_FORCE_ABORT: ctx->debug_force_abort = value != 0; return RT_OK;
         default: return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
     }
 }
@@ -1000,6 +1022,12 @@ int rt_fetch_stats(rt_ctx* ctx, rt_stats* out) {
     if (ctx == nullptr || out == nullptr) return RT_ERR_INVALID_ARGUMENT;
     RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return read_stats(ctx, out);
+}
+
+int rt_launch_status(rt_ctx* ctx) {
+    if (ctx == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_status(ctx);
 }
 
 int rt_photon_download(rt_ctx* ctx, uint32_t object_index, float* rgba_out) {

@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
     if (threadIdx.x == 0) {
         sh.ctl[0] = sh.ctl[1] = sh.ctl[2] = sh.ctl[3] = 0u;
         sh.tracers_done = 0u;
-        sh.abort = 0u;
+        sh.abort = (job.debug_abort != 0u && blockIdx.x == 0) ? 1u : 0u;   // RT_OPT_DEBUG_FORCE_ABORT
         sh.hungry = 1u;
         sh.pad = 0u;
     }

@@ -161,6 +161,8 @@ struct DevJob {
     uint32_t static_blocks;      // 64-id blocks every wave owns outright: wave w of n_waves owns blocks w, w + n_waves, ...
     uint32_t n_waves;
     uint64_t dyn_base;           // first id handed out through queue_head
+    uint32_t debug_abort;        // RT_OPT_DEBUG_FORCE_ABORT: trace_julia_kernel's first workgroup raises its watchdog flag at once
+    uint32_t pad0;
 };
 
 // Photon emission job (src/photonmap.cpp:38-57)

@@ -78,6 +78,8 @@ class HipRenderer:
         out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         if n:
             self.ctx.render_device(out.data_ptr(), stream, bands)
+            if scene.desc.n_julias > 0:
+                self.ctx.launch_status()     # an abandoned Julia launch must not reach the gather as a picture
         return out
 
     def mul_add(self, acc, src, factor):

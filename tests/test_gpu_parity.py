@@ -160,7 +160,8 @@ def test_c3_fresnel_ss4_full_size(hip_ctx):
     z = np.load(golden_path("c3_fresnel_ss4.rows.npz"))
     assert np.array_equal(img[z["rows0"]].view(np.uint32), z["data0"].view(np.uint32))
     gold, _n = capi.png_read(golden_path("c3_fresnel_ss4.png"))
-    assert_north_star(capi.quantize(img), gold, "c3 ss4")
+    d = assert_north_star(capi.quantize(img), gold, "c3 ss4")
+    assert d["max"] == 0
 
 
 def test_c4_julia_full_size(hip_ctx):
@@ -170,8 +171,36 @@ def test_c4_julia_full_size(hip_ctx):
     z = np.load(golden_path("c4_julia_shiny.rows.npz"))
     assert np.array_equal(img[z["rows0"]].view(np.uint32), z["data0"].view(np.uint32))
     gold, _n = capi.png_read(golden_path("c4_julia_shiny.png"))
-    assert_north_star(capi.quantize(img), gold, "c4 julia")
+    d = assert_north_star(capi.quantize(img), gold, "c4 julia")
+    assert d["max"] == 0
     assert st.julia_queries > 0 and st.julia_steps > st.julia_queries
+
+
+def test_abandoned_julia_launch_is_an_error_on_every_path(hip_ctx):
+    """The Julia kernel's watchdog (a wave stuck on the job queues gives the launch up) must reach the caller as an
+    error, not as a partly rendered picture: rt_render with stats == NULL (what the CLI shim calls), and
+    rt_launch_status after rt_render_device (what the multi-GPU driver and bench.py call)."""
+    import torch
+    sc = capi.Scene(scene_path("examples2/4_julia.xml"), 0.0)
+    sc.set_camera(96, 64, 0)
+    hip_ctx.upload(sc)
+    hip_ctx.set_option(capi.RT_OPT_COLLECT_STATS, 0)
+    lib = capi.hip_lib()
+    out = np.zeros((64 * 96, 4), dtype=np.float32)
+    try:
+        hip_ctx.set_option(capi.RT_OPT_DEBUG_FORCE_ABORT, 1)
+        rc = lib.rt_render(hip_ctx._ctx, None, out.ctypes.data, None)
+        assert rc == -3 and b"abandoned" in lib.rt_last_error(hip_ctx._ctx)
+        dev = torch.empty((64 * 96, 4), dtype=torch.float32, device="cuda:0")
+        hip_ctx.render_device(dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        with pytest.raises(capi.RtError, match="abandoned"):
+            hip_ctx.launch_status()
+    finally:
+        hip_ctx.set_option(capi.RT_OPT_DEBUG_FORCE_ABORT, 0)
+    # the flag does not outlive its report: the next launch is clean and complete
+    img, _ = hip_ctx.render()
+    ref, _ = oracle_lib.render(sc, None, threads=16)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
 
 
 def test_julia_small_vs_oracle(hip_ctx):
