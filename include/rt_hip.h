@@ -220,6 +220,22 @@ int rt_render(rt_ctx* ctx, const rt_bands* bands_or_null, float* rgba_out, rt_st
 int rt_render_device(rt_ctx* ctx, const rt_bands* bands_or_null, void* d_rgba_out, void* hip_stream);
 int rt_photon_generate_device(rt_ctx* ctx, void* hip_stream);
 int rt_fetch_stats(rt_ctx* ctx, rt_stats* out);
+
+/* rt_render_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  NO counterpart in the reference.  Same arguments, same picture bit for
+ * bit; but the launch works in a fixed workspace — a file-scope __device__ array of RT_NOALLOC_SCRATCH_BYTES that
+ * every GPU holds from the moment it loads the library until the process ends — instead of the context's own
+ * buffers, and the call makes no hipMalloc, hipFree or other allocating call.  The workspace holds the work queue
+ * words, the frame's sample buffer ([samples per pixel][pixels] float4, only when supersampling or dispersion give
+ * more than one sample per pixel) and the per-lane ray-tree frame stacks; when the stacks of a full persistent grid
+ * do not fit, fewer workgroups are launched (slower, same result).  RT_ERR_LIMIT with a message that names the
+ * sizes when the sample buffer, or the stacks of a single workgroup, do not fit.  Counters are not collected
+ * (RT_OPT_COLLECT_STATS is ignored).  ALL calls on one GPU share that GPU's workspace: two calls that overlap in
+ * time on one GPU (two streams, two contexts, two threads) race.  rt_launch_status applies as for rt_render_device. */
+#ifndef RT_NOALLOC_SCRATCH_BYTES
+#define RT_NOALLOC_SCRATCH_BYTES (32u << 20)
+#endif
+int rt_render_device_noalloc(rt_ctx* ctx, const rt_bands* bands_or_null, void* d_rgba_out, void* hip_stream);
 /* Waits for the last rt_render_device launch on this context and returns RT_ERR_HIP if the Julia kernel's watchdog
  * abandoned it (a wave waited too long on the job queues; the picture is incomplete), else RT_OK.  rt_render and
  * rt_fetch_stats make the same check themselves.  Callers of rt_render_device call this before they use the picture.

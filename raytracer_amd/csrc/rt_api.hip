@@ -51,6 +51,25 @@ struct Buffer {
     size_t bytes = 0;
 };
 
+// Device memory a render launch works in besides the scene and its output.
+struct Workspace {
+    unsigned long long* queue = nullptr;      // [0] queue head, [1] watchdog flag of trace_julia_kernel
+    unsigned long long* counters = nullptr;   // C_COUNT words
+    float* stack = nullptr;                   // per-lane DFS frames
+    size_t stack_bytes = 0;                   // capacity
+    float4* samples = nullptr;                // [samples_per_pixel][pixels] when samples_per_pixel > 1
+    size_t samples_bytes = 0;                 // capacity
+};
+
+// ---- rt_render_device_noalloc: the workspace of the entry point that allocates nothing --------------------------
+// One array per GPU that loads this library, held until the process ends.  Host code never passes `scratch` itself
+// to a kernel or a memset (its name is a host-side stand-in, not a device address): rt_create asks the runtime for
+// the array's address on ITS device (hipGetSymbolAddress) and every use goes through that pointer.
+constexpr size_t kNoAllocScratchBytes = size_t(RT_NOALLOC_SCRATCH_BYTES);
+constexpr size_t kNoAllocHeaderBytes = 4096;   // queue words at 0, counters at 256
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+static_assert(C_COUNT * sizeof(unsigned long long) + 256 <= kNoAllocHeaderBytes, "scratch header");
+
 }  // namespace
 
 struct rt_ctx {
@@ -93,6 +112,11 @@ struct rt_ctx {
     unsigned long long* h_status = nullptr;     // pinned copy of d_queue[1], written by the stream after every render launch
     bool status_pending = false;                // a render launch whose watchdog word has not been looked at yet
     bool debug_force_abort = false;             // RT_OPT_DEBUG_FORCE_ABORT
+    unsigned long long* status_flag = nullptr;  // device word the pending status was copied from (cleared once seen)
+    unsigned char* noalloc_scratch = nullptr;   // address of `scratch` on this context's device (hipGetSymbolAddress)
+    // persistent grid of the render kernels for the uploaded scene ([0] plain, [1] counters build): asked once per upload
+    int trace_blocks_per_cu[2] = {0, 0};
+    int julia_blocks_per_cu[2] = {0, 0};
     unsigned long long* d_counters = nullptr;   // rt_stats words
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool events_pending = false;
@@ -195,46 +219,58 @@ int persistent_grid(rt_ctx* ctx, K kernel, uint64_t work_items, int* blocks, siz
     return RT_OK;
 }
 
-int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_t stream) {
+// Enqueues one render.  `fixed` == NULL: the context's own buffers, grown on demand (hipMalloc).  Otherwise the launch
+// is fitted into the given workspace and nothing is allocated: fewer persistent workgroups when the frame stacks of
+// a full grid do not fit, RT_ERR_LIMIT when not even one workgroup or the sample buffer fits.
+int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_t stream, const Workspace* fixed = nullptr) {
     if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_render before rt_scene_upload");
     if (bands && (bands->band_rows == 0 || bands->band_stride == 0)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_bands: band_rows and band_stride must be > 0");
     DevJob job;
     make_job(ctx, bands, &job);
     if (job.n_pixels == 0) return RT_OK;
     const bool julia = ctx->dev.n_julias > 0;
-    const bool stats = ctx->collect_stats;
+    const bool stats = ctx->collect_stats && fixed == nullptr;
     int blocks = 0;
     int rc;
     DevScene dev = ctx->dev;
     if (julia && dev.shade_blob_bytes > kMaxLdsBlobBytesJulia) dev.shade_blob_in_lds = 0;
     const size_t lds = dev.shade_blob_in_lds ? dev.shade_blob_bytes : 0;
-    uint64_t lanes;
-    if (julia) {
-        // one workgroup of tracer and marcher waves per CU (trace_julia_kernel)
-        int per_cu = 0;
-        if (stats) RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_julia_kernel<true>, kJuliaBlockThreads, lds));
-        else RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_julia_kernel<false>, kJuliaBlockThreads, lds));
-        if (per_cu < 1) return fail(ctx, RT_ERR_HIP, "trace_julia_kernel does not fit a compute unit");
-        if (lds > 0) {
-            // static + dynamic LDS exceeds 64 KB: opt in (gfx950 has 160 KB per CU)
-            if (stats) RT_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_julia_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-            else RT_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_julia_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        }
-        const uint64_t needed = (job.n_samples + kJuliaTracerLanesHost - 1) / kJuliaTracerLanesHost;
-        blocks = static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(ctx->n_cus), needed ? needed : 1));
-        lanes = static_cast<uint64_t>(blocks) * kJuliaTracerLanesHost;
+    const uint64_t block_lanes = julia ? kJuliaTracerLanesHost : 256;
+    {
+        const int per_cu = julia ? std::min(1, ctx->julia_blocks_per_cu[stats]) : ctx->trace_blocks_per_cu[stats];
+        if (per_cu < 1) return fail(ctx, RT_ERR_HIP, "%s does not fit a compute unit", julia ? "trace_julia_kernel" : "trace_kernel");
+        const uint64_t needed = (job.n_samples + block_lanes - 1) / block_lanes;
+        blocks = static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(ctx->n_cus) * per_cu, needed)));
+    }
+    const size_t frame_bytes_per_lane = static_cast<size_t>(ctx->dev.max_bounces + 1) * kFrameFieldsHost * sizeof(float);
+    const size_t samples_bytes = job.samples_per_pixel > 1 ? job.n_pixels * job.samples_per_pixel * sizeof(float4) : 0;
+    Workspace ws;
+    if (fixed != nullptr) {
+        ws = *fixed;
+        if (samples_bytes > ws.samples_bytes)
+            return fail(ctx, RT_ERR_LIMIT, "rt_render_device_noalloc: the sample buffer of this frame (%zu bytes: %llu pixels x %u samples) exceeds the %zu bytes the fixed workspace has for it",
+                        samples_bytes, static_cast<unsigned long long>(job.n_pixels), job.samples_per_pixel, ws.samples_bytes);
+        const uint64_t fit = ws.stack_bytes / (block_lanes * frame_bytes_per_lane);
+        if (fit < 1)
+            return fail(ctx, RT_ERR_LIMIT, "rt_render_device_noalloc: the frame stacks of one workgroup (%zu bytes at max_bounces %u) exceed the fixed workspace",
+                        static_cast<size_t>(block_lanes * frame_bytes_per_lane), ctx->dev.max_bounces);
+        if (static_cast<uint64_t>(blocks) > fit) blocks = static_cast<int>(fit);
     } else {
-        rc = stats ? persistent_grid(ctx, trace_kernel<true>, job.n_samples, &blocks, lds) : persistent_grid(ctx, trace_kernel<false>, job.n_samples, &blocks, lds);
-        if (rc != RT_OK) return rc;
-        lanes = static_cast<uint64_t>(blocks) * 256;
+        ws.queue = ctx->d_queue;
+        ws.counters = ctx->d_counters;
     }
-    rc = grow(ctx, ctx->stack, lanes * (ctx->dev.max_bounces + 1) * kFrameFieldsHost * sizeof(float));
-    if (rc != RT_OK) return rc;
-    if (job.samples_per_pixel > 1) {
-        rc = grow(ctx, ctx->samples, job.n_pixels * job.samples_per_pixel * sizeof(float4));
+    const uint64_t lanes = static_cast<uint64_t>(blocks) * block_lanes;
+    if (fixed == nullptr) {
+        rc = grow(ctx, ctx->stack, lanes * frame_bytes_per_lane);
         if (rc != RT_OK) return rc;
-        job.samples = static_cast<float4*>(ctx->samples.ptr);
+        ws.stack = static_cast<float*>(ctx->stack.ptr);
+        if (samples_bytes > 0) {
+            rc = grow(ctx, ctx->samples, samples_bytes);
+            if (rc != RT_OK) return rc;
+            ws.samples = static_cast<float4*>(ctx->samples.ptr);
+        }
     }
+    if (job.samples_per_pixel > 1) job.samples = ws.samples;
     job.out = d_out;
     job.id_chunk = 1;   // see fetch_ids
     job.n_waves = static_cast<uint32_t>(lanes / 64);
@@ -245,13 +281,19 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     job.static_blocks = tiny ? static_cast<uint32_t>((job.n_samples / 64 + lanes / 64 - 1) / (lanes / 64))
                              : static_blocks_per_wave(job.n_samples, lanes, RT_STATIC_SHARE_TRACE);
     job.dyn_base = static_cast<uint64_t>(job.n_waves) * job.static_blocks * 64ull;
-    job.stack = static_cast<float*>(ctx->stack.ptr);
-    job.queue_head = ctx->d_queue;
-    job.counters = ctx->d_counters;
+    job.stack = ws.stack;
+    job.queue_head = ws.queue;
+    job.counters = ws.counters;
     job.debug_abort = ctx->debug_force_abort ? 1u : 0u;
-    // [0] queue head: cleared per launch.  [1] watchdog flag: sticky, cleared only once the host has seen it (launch_status)
-    RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), stream));
-    RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long), stream));
+    if (fixed != nullptr) {
+        // the fixed workspace is shared by every call on this GPU and keeps the last call's contents: both queue
+        // words and the counters start at zero (the frame stacks and the sample buffer are written before they are read)
+        RT_HIP_TRY(ctx, hipMemsetAsync(ws.queue, 0, kNoAllocHeaderBytes, stream));
+    } else {
+        // [0] queue head: cleared per launch.  [1] watchdog flag: sticky, cleared only once the host has seen it (launch_status)
+        RT_HIP_TRY(ctx, hipMemsetAsync(ws.queue, 0, sizeof(unsigned long long), stream));
+        RT_HIP_TRY(ctx, hipMemsetAsync(ws.counters, 0, C_COUNT * sizeof(unsigned long long), stream));
+    }
     RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
     if (julia) {
         if (stats) hipLaunchKernelGGL((trace_julia_kernel<true>), dim3(blocks), dim3(kJuliaBlockThreads), lds, stream, dev, job);
@@ -266,10 +308,11 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
         hipLaunchKernelGGL(sum_samples_kernel, dim3(g), dim3(256), 0, stream, job.samples, job.out, job.n_pixels, job.samples_per_pixel, ctx->dev.inv_samples);
         RT_HIP_TRY(ctx, hipGetLastError());
     }
-    if (julia) RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_queue + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    if (julia) RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ws.queue + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream));
     ctx->events_pending = true;
     ctx->status_pending = julia;
+    ctx->status_flag = ws.queue + 1;
     return RT_OK;
 }
 
@@ -281,7 +324,7 @@ int launch_status(rt_ctx* ctx) {
     ctx->status_pending = false;
     if (*ctx->h_status == 0) return RT_OK;
     *ctx->h_status = 0;
-    RT_HIP_TRY(ctx, hipMemset(ctx->d_queue + 1, 0, sizeof(unsigned long long)));
+    RT_HIP_TRY(ctx, hipMemset(ctx->status_flag, 0, sizeof(unsigned long long)));
     return fail(ctx, RT_ERR_HIP, "trace_julia_kernel: a wave waited too long on the job queues and the launch was abandoned");
 }
 
@@ -497,6 +540,17 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
         hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) {
         delete ctx;
         return fail(nullptr, RT_ERR_HIP, "cannot allocate context resources on device %d", device_id);
+    }
+    {
+        // this device's copy of `scratch` (every GPU that loads the code object holds its own, at its own address)
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || p == nullptr) {
+            const int rc = fail(nullptr, RT_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d: %s", device_id, hipGetErrorString(e));
+            delete ctx;
+            return rc;
+        }
+        ctx->noalloc_scratch = static_cast<unsigned char*>(p);
     }
     (void)hipMemset(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long));
     (void)hipMemset(ctx->d_queue, 0, 256);   // [0] queue head, [1] watchdog flag of trace_julia_kernel
@@ -944,6 +998,23 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
         RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_point_lights), (ctx->point_lights.size() + 1) * sizeof(uint32_t)));
         if (!ctx->point_lights.empty()) RT_HIP_TRY(ctx, hipMemcpy(ctx->d_point_lights, ctx->point_lights.data(), ctx->point_lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    {
+        // persistent-grid sizes of the render kernels for this scene (the LDS copy of the shade blob decides), asked
+        // once per upload so that a render call makes no runtime query (rt_render_device_noalloc makes none at all)
+        const size_t lds_t = sc.shade_blob_in_lds ? sc.shade_blob_bytes : 0;
+        const size_t lds_j = (sc.shade_blob_in_lds && sc.shade_blob_bytes <= kMaxLdsBlobBytesJulia) ? sc.shade_blob_bytes : 0;
+        RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->trace_blocks_per_cu[0], trace_kernel<false>, 256, lds_t));
+        RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->trace_blocks_per_cu[1], trace_kernel<true>, 256, lds_t));
+        if (sc.n_julias > 0) {
+            if (lds_j > 0) {
+                // static + dynamic LDS exceeds 64 KB: opt in (gfx950 has 160 KB per CU)
+                RT_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_julia_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_j)));
+                RT_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_julia_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_j)));
+            }
+            RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->julia_blocks_per_cu[0], trace_julia_kernel<false>, kJuliaBlockThreads, lds_j));
+            RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->julia_blocks_per_cu[1], trace_julia_kernel<true>, kJuliaBlockThreads, lds_j));
+        }
+    }
     ctx->n_objects = d->n_objects;
     ctx->has_scene = true;
     return RT_OK;
@@ -1001,6 +1072,29 @@ int rt_render_device(rt_ctx* ctx, const rt_bands* bands, void* d_rgba_out, void*
     if (d_rgba_out == nullptr) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render_device: output pointer is NULL");
     RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return render_enqueue(ctx, bands, static_cast<float4*>(d_rgba_out), static_cast<hipStream_t>(hip_stream));
+}
+
+int rt_render_device_noalloc(rt_ctx* ctx, const rt_bands* bands, void* d_rgba_out, void* hip_stream) {
+    if (ctx == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    if (d_rgba_out == nullptr) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render_device_noalloc: output pointer is NULL");
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_render_device_noalloc before rt_scene_upload");
+    // carve the fixed workspace: header | sample buffer of this frame | frame stacks (whatever is left)
+    const uint64_t n_pixels = rt_bands_pixel_count(ctx->dev.width, ctx->dev.height, bands);
+    const uint64_t spp = static_cast<uint64_t>(ctx->dev.supersampling) * ctx->dev.supersampling * (ctx->dev.dispersion ? 8u : 1u);
+    const uint64_t room = kNoAllocScratchBytes - kNoAllocHeaderBytes;
+    uint64_t samples_bytes = spp > 1 ? n_pixels * spp * sizeof(float4) : 0;
+    samples_bytes = (samples_bytes + 255) & ~uint64_t(255);
+    Workspace ws;
+    unsigned char* base = ctx->noalloc_scratch;   // never the array's name: see `scratch`
+    ws.queue = reinterpret_cast<unsigned long long*>(base);
+    ws.counters = reinterpret_cast<unsigned long long*>(base + 256);
+    ws.samples = reinterpret_cast<float4*>(base + kNoAllocHeaderBytes);
+    ws.samples_bytes = static_cast<size_t>(std::min<uint64_t>(samples_bytes, room));
+    ws.stack = reinterpret_cast<float*>(base + kNoAllocHeaderBytes + ws.samples_bytes);
+    ws.stack_bytes = static_cast<size_t>(room - ws.samples_bytes);
+    if (samples_bytes > room) ws.samples_bytes = static_cast<size_t>(room), ws.stack_bytes = 0;   // render_enqueue reports the limit
+    return render_enqueue(ctx, bands, static_cast<float4*>(d_rgba_out), static_cast<hipStream_t>(hip_stream), &ws);
 }
 
 int rt_render(rt_ctx* ctx, const rt_bands* bands, float* rgba_out, rt_stats* stats) {
