@@ -36,8 +36,8 @@ hipError_t photon_order_reduce(const unsigned long long* keys, const float4* val
                                unsigned* long_runs, unsigned long long* words, void* temp, size_t temp_bytes, hipStream_t stream);
 constexpr int kFrameFieldsHost = 11;
 constexpr size_t kMaxLdsBlobBytes = 28 * 1024;   // + 11 KB of frame tops: keeps 4 blocks per CU within the 160 KB LDS
-constexpr size_t kMaxLdsBlobBytesJulia = 24 * 1024;   // trace_julia_kernel: one workgroup per CU, 68 KB of its own LDS   // trace_julia_kernel: blob + its queues stay under 64 KB
-constexpr int kJuliaBlockThreads = kJuliaWaves * 64, kJuliaTracerLanesHost = (kJuliaWaves - kJuliaMarcherWaves) * 64;
+constexpr int kFrameRecordWordsHost = 12;       // trace_julia_kernel keeps every frame as a 48-byte record of its own
+constexpr int kJuliaBlockThreads = kJuliaWaves * 64, kJuliaShaderWavesHost = kJuliaWaves - kJuliaMarcherWaves;
 }  // namespace rtd
 
 using namespace rtd;
@@ -233,16 +233,16 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     int blocks = 0;
     int rc;
     DevScene dev = ctx->dev;
-    if (julia && dev.shade_blob_bytes > kMaxLdsBlobBytesJulia) dev.shade_blob_in_lds = 0;
+    if (julia) dev.shade_blob_in_lds = 0;     // trace_julia_kernel's LDS belongs to its ray pool
     const size_t lds = dev.shade_blob_in_lds ? dev.shade_blob_bytes : 0;
-    const uint64_t block_lanes = julia ? kJuliaTracerLanesHost : 256;
+    const uint64_t block_lanes = julia ? kJuliaPoolContexts : 256;   // ray trees in flight per workgroup
     {
         const int per_cu = julia ? std::min(1, ctx->julia_blocks_per_cu[stats]) : ctx->trace_blocks_per_cu[stats];
         if (per_cu < 1) return fail(ctx, RT_ERR_HIP, "%s does not fit a compute unit", julia ? "trace_julia_kernel" : "trace_kernel");
         const uint64_t needed = (job.n_samples + block_lanes - 1) / block_lanes;
         blocks = static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(ctx->n_cus) * per_cu, needed)));
     }
-    const size_t frame_bytes_per_lane = static_cast<size_t>(ctx->dev.max_bounces + 1) * kFrameFieldsHost * sizeof(float);
+    const size_t frame_bytes_per_lane = static_cast<size_t>(ctx->dev.max_bounces + 1) * (julia ? kFrameRecordWordsHost : kFrameFieldsHost) * sizeof(float);
     const size_t samples_bytes = job.samples_per_pixel > 1 ? job.n_pixels * job.samples_per_pixel * sizeof(float4) : 0;
     Workspace ws;
     if (fixed != nullptr) {
@@ -273,13 +273,15 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     if (job.samples_per_pixel > 1) job.samples = ws.samples;
     job.out = d_out;
     job.id_chunk = 1;   // see fetch_ids
-    job.n_waves = static_cast<uint32_t>(lanes / 64);
+    // waves that draw sample ids: every wave of trace_kernel, the shader waves of trace_julia_kernel
+    const uint64_t id_lanes = julia ? static_cast<uint64_t>(blocks) * kJuliaShaderWavesHost * 64 : lanes;
+    job.n_waves = static_cast<uint32_t>(id_lanes / 64);
     // a quarter of the tiles is owned outright (measured on C2, whose 16 MB texture likes the waves to
     // sweep the image together: 0/16 2.24 ms, 4/16 2.16, 8/16 2.60, 12/16 2.86; C3: 12.3, 11.5, 11.2, 11.5);
     // a launch of at most two tiles per wave needs no counter at all (C1: 0.10 -> 0.06 ms)
-    const bool tiny = job.n_samples / 64 <= 2 * (lanes / 64);
-    job.static_blocks = tiny ? static_cast<uint32_t>((job.n_samples / 64 + lanes / 64 - 1) / (lanes / 64))
-                             : static_blocks_per_wave(job.n_samples, lanes, RT_STATIC_SHARE_TRACE);
+    const bool tiny = job.n_samples / 64 <= 2 * (id_lanes / 64);
+    job.static_blocks = tiny ? static_cast<uint32_t>((job.n_samples / 64 + id_lanes / 64 - 1) / (id_lanes / 64))
+                             : static_blocks_per_wave(job.n_samples, id_lanes, RT_STATIC_SHARE_TRACE);
     job.dyn_base = static_cast<uint64_t>(job.n_waves) * job.static_blocks * 64ull;
     job.stack = ws.stack;
     job.queue_head = ws.queue;
@@ -1002,17 +1004,11 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
         // persistent-grid sizes of the render kernels for this scene (the LDS copy of the shade blob decides), asked
         // once per upload so that a render call makes no runtime query (rt_render_device_noalloc makes none at all)
         const size_t lds_t = sc.shade_blob_in_lds ? sc.shade_blob_bytes : 0;
-        const size_t lds_j = (sc.shade_blob_in_lds && sc.shade_blob_bytes <= kMaxLdsBlobBytesJulia) ? sc.shade_blob_bytes : 0;
         RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->trace_blocks_per_cu[0], trace_kernel<false>, 256, lds_t));
         RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->trace_blocks_per_cu[1], trace_kernel<true>, 256, lds_t));
         if (sc.n_julias > 0) {
-            if (lds_j > 0) {
-                // static + dynamic LDS exceeds 64 KB: opt in (gfx950 has 160 KB per CU)
-                RT_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_julia_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_j)));
-                RT_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_julia_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_j)));
-            }
-            RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->julia_blocks_per_cu[0], trace_julia_kernel<false>, kJuliaBlockThreads, lds_j));
-            RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->julia_blocks_per_cu[1], trace_julia_kernel<true>, kJuliaBlockThreads, lds_j));
+            RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->julia_blocks_per_cu[0], trace_julia_kernel<false>, kJuliaBlockThreads, 0));
+            RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->julia_blocks_per_cu[1], trace_julia_kernel<true>, kJuliaBlockThreads, 0));
         }
     }
     ctx->n_objects = d->n_objects;

@@ -105,18 +105,12 @@ struct Lane {
     unsigned n_obj;
     float acc[3], matcol[3];
     unsigned li;
-    // the newest frame of the DFS stack is kept in LDS; HBM only holds the frames below it
-    // (written when a deeper frame is pushed, prefetched back when the top is popped)
-    float* top_base;         // this lane's column of the workgroup's LDS array [field][lane] (11 KB per 256 lanes;
-    unsigned top_stride;     // in registers it was the first thing the compiler spilled to scratch)
     // sample
     unsigned sp;             // frames on the stack == depth of the current node
     float wavelength;
     int hue;                 // -1 without dispersion
     unsigned long long out_slot;
 };
-
-RT_DEV float& top_of(Lane& L, int c) { return L.top_base[c * L.top_stride]; }
 
 template <bool STATS>
 RT_DEV void bump(Counters& n, int slot, unsigned long long by = 1) {
@@ -375,6 +369,40 @@ struct FrameRef {
     RT_DEV float& at(unsigned frame, int field) const { return base[(static_cast<unsigned long long>(frame) * kFrameFields + field) * stride]; }
 };
 
+// Where a lane's DFS frames live.  resolve_lane only sees this interface: frame f of the lane, field c.
+//   TopInLds   (trace_kernel, photon-free lockstep lanes): the newest frame is kept in the workgroup's LDS array
+//              [field][lane] (in registers it was the first thing the compiler spilled to scratch); HBM holds the
+//              frames below it, [frame][field][grid lane] so that a wave's accesses coalesce.
+//   FramesInHbm (trace_julia_kernel's ray pool): a context is handled by whichever wave pops it, so every frame is a
+//              48-byte record of its own in HBM, [context][frame][field]: a lane touches one or two cache lines per push/pop.
+struct TopInLds {
+    float* top;              // this lane's column of the LDS array
+    unsigned top_stride;
+    FrameRef below;
+    RT_DEV float get(unsigned, int c) const { return top[c * top_stride]; }
+    RT_DEV void set(unsigned, int c, float v) const { top[c * top_stride] = v; }
+    RT_DEV void before_push(unsigned f) const {      // frame f becomes the top: the old top moves to HBM
+        if (f > 0) {
+#pragma unroll
+            for (int c = 0; c < kFrameFields; c++) below.at(f - 1, c) = top[c * top_stride];
+        }
+    }
+    RT_DEV void after_pop(unsigned f) const {        // frame f is gone: frame f-1 comes back as the top
+        if (f > 0) {
+#pragma unroll
+            for (int c = 0; c < kFrameFields; c++) top[c * top_stride] = below.at(f - 1, c);
+        }
+    }
+};
+constexpr int kFrameRecordWords = 12;
+struct FramesInHbm {
+    float* rec;              // this context's records
+    RT_DEV float get(unsigned f, int c) const { return rec[f * kFrameRecordWords + c]; }
+    RT_DEV void set(unsigned f, int c, float v) const { rec[f * kFrameRecordWords + c] = v; }
+    RT_DEV void before_push(unsigned) const {}
+    RT_DEV void after_pop(unsigned) const {}
+};
+
 // ---- sample queue ---------------------------------------------------------------------------------
 // Lanes with `need` set get consecutive sample ids.  Most ids are owned outright: wave w of W owns the
 // 64-id blocks w, w + W, w + 2W ... (interleaved: a contiguous range per wave would hand whole image
@@ -517,8 +545,8 @@ RT_DEV void mark(Counters& n, long long& t, int slot) {
 }
 
 // ---- resolve phase: advance one lane's ray tree by one query result ---------------------------------
-template <bool STATS>
-RT_DEV void resolve_lane(const DevScene& sc, const ShadeTables& T, const DevJob& job, const FrameRef& stack, Lane& L, Counters& n,
+template <bool STATS, typename Frames>
+RT_DEV void resolve_lane(const DevScene& sc, const ShadeTables& T, const DevJob& job, const Frames& frames, Lane& L, Counters& n,
                          bool& sample_done, Col& sample_value) {
     bool lights_done = false;
     bool returning = false;
@@ -647,22 +675,19 @@ RT_DEV void resolve_lane(const DevScene& sc, const ShadeTables& T, const DevJob&
                 if (want_refl) reflection_ray(L.n_dir, L.n_point, L.n_normal, L.n_cos, mo, md);
                 if (refr_ok || want_refl) {
                     const unsigned f = L.sp;
-                    if (f > 0) {
-#pragma unroll
-                        for (int c = 0; c < kFrameFields; c++) stack.at(f - 1, c) = top_of(L, c);   // spill the old top
-                    }
-                    top_of(L, 0) = L.acc[0];
-                    top_of(L, 1) = L.acc[1];
-                    top_of(L, 2) = L.acc[2];
-                    top_of(L, 3) = kr;
-                    top_of(L, 4) = mo.x;
-                    top_of(L, 5) = mo.y;
-                    top_of(L, 6) = mo.z;
-                    top_of(L, 7) = md.x;
-                    top_of(L, 8) = md.y;
-                    top_of(L, 9) = md.z;
+                    frames.before_push(f);
+                    frames.set(f, 0, L.acc[0]);
+                    frames.set(f, 1, L.acc[1]);
+                    frames.set(f, 2, L.acc[2]);
+                    frames.set(f, 3, kr);
+                    frames.set(f, 4, mo.x);
+                    frames.set(f, 5, mo.y);
+                    frames.set(f, 6, mo.z);
+                    frames.set(f, 7, md.x);
+                    frames.set(f, 8, md.y);
+                    frames.set(f, 9, md.z);
                     // flags: bit0 = the child now in flight is the reflection, bit1 = reflection still to do
-                    top_of(L, 10) = __uint_as_float(refr_ok ? (want_refl ? 2u : 0u) : 1u);
+                    frames.set(f, 10, __uint_as_float(refr_ok ? (want_refl ? 2u : 0u) : 1u));
                     L.sp = f + 1;
                     if (refr_ok) begin_query(L, ro, rd, kInfinite, Q_TRACE); else begin_query(L, mo, md, kInfinite, Q_TRACE);
                     descended = true;
@@ -687,23 +712,20 @@ RT_DEV void resolve_lane(const DevScene& sc, const ShadeTables& T, const DevJob&
             return;
         }
         const unsigned f = L.sp - 1;
-        const unsigned flags = __float_as_uint(top_of(L, 10));
-        const float kr = top_of(L, 3);
+        const unsigned flags = __float_as_uint(frames.get(f, 10));
+        const float kr = frames.get(f, 3);
         const float w = (flags & 1u) ? kr : 1.0f - kr;
         float acc[3];
-        for (int c = 0; c < 3; c++) acc[c] = top_of(L, c) + val[c] * w;
+        for (int c = 0; c < 3; c++) acc[c] = frames.get(f, c) + val[c] * w;
         if (flags & 2u) {
             // refraction child done, reflection child next
-            for (int c = 0; c < 3; c++) top_of(L, c) = acc[c];
-            top_of(L, 10) = __uint_as_float(1u);
-            begin_query(L, v3(top_of(L, 4), top_of(L, 5), top_of(L, 6)), v3(top_of(L, 7), top_of(L, 8), top_of(L, 9)), kInfinite, Q_TRACE);
+            for (int c = 0; c < 3; c++) frames.set(f, c, acc[c]);
+            frames.set(f, 10, __uint_as_float(1u));
+            begin_query(L, v3(frames.get(f, 4), frames.get(f, 5), frames.get(f, 6)), v3(frames.get(f, 7), frames.get(f, 8), frames.get(f, 9)), kInfinite, Q_TRACE);
             mark<STATS>(n, t_sec, D_R_RETURN_CYCLES);
             return;
         }
-        if (f > 0) {
-#pragma unroll
-            for (int c = 0; c < kFrameFields; c++) top_of(L, c) = stack.at(f - 1, c);   // prefetch the new top
-        }
+        frames.after_pop(f);
         L.sp = f;
         val[0] = acc[0];
         val[1] = acc[1];
@@ -747,8 +769,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
 
     Lane L;
     __shared__ float top_store[kFrameFields * 256];
-    L.top_base = top_store + threadIdx.x;
-    L.top_stride = 256;
+    const TopInLds frames = {top_store + threadIdx.x, 256u, stack};
     L.state = S_RESOLVE;       // "resolve" of a lane without a sample = fetch one
     L.qkind = -1;
     L.sp = 0;
@@ -780,7 +801,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
             const bool mine = L.state == S_RESOLVE;
             bool done = false;
             Col value = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (mine && !fresh) resolve_lane<STATS>(sc, T, job, stack, L, n, done, value);
+            if (mine && !fresh) resolve_lane<STATS>(sc, T, job, frames, L, n, done, value);
             t_fetch_outer = STATS ? clock64() : 0;
             if (mine && done) store_sample(sc, job, L, value);
             if (mine && (fresh || done)) {
@@ -814,63 +835,68 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
     flush_counters<STATS>(n, job.counters);
 }
 
-// ---- the render kernel for scenes with Julia sets -------------------------------------------------------
-// Marching a Julia set costs 10^2..10^6 times what the rest of a ray's life costs, and a march step's
-// own cost (iterations of the distance estimator) varies by 10x from lane to lane.  So the work is
-// split by ROLE inside a workgroup of kJuliaWaves waves:
-//   * tracer waves own rays (one per lane, exactly as trace_kernel does) and run the query / resolve
-//     phases; a ray that enters a Julia set's bounding sphere becomes a JOB in LDS (one record per
-//     owner lane) whose owner id is pushed on a ring in LDS, and the lane waits;
-//   * marcher waves (one per SIMD) pop jobs into ALL 64 lanes and march them; a lane that finishes a
-//     job takes the next one at once, so the march loop always runs full.  The estimator's iterations
-//     run in blocks of four for the wave; lanes whose estimate is complete take their march step
-//     (tail + advance) together as soon as a kJuliaStepDivisor-th of the lanes wait for one;
-//   * converged jobs go to a second ring and are finished (normal estimate, world-space hit) 64 at a
-//     time by whichever marcher finds a full batch, or a partial one when it has nothing else to do.
-// Queues, job records and results never leave LDS; HBM only sees the sample buffer and frame stacks.
-constexpr int kJuliaTracerLanes = (kJuliaWaves - kJuliaMarcherWaves) * 64;   // owners per workgroup
-constexpr unsigned kJuliaQueueCap = kJuliaTracerLanes <= 512 ? 512u : 1024u;    // an owner has at most one job in flight
-static_assert(sizeof(float) * (11 + 11) * kJuliaTracerLanes + 16 * kJuliaQueueCap + 64 <= kJuliaStaticLdsBytes, "kJuliaStaticLdsBytes");
-static_assert(kJuliaQueueCap >= kJuliaTracerLanes && (kJuliaQueueCap & (kJuliaQueueCap - 1)) == 0, "ring size");
-#ifndef RT_JULIA_FUSE_QUERY
-#define RT_JULIA_FUSE_QUERY 1
-#endif
+// ---- the render kernel for scenes with Julia sets: a ray pool with queues by kind -----------------------
+// Marching a Julia set costs 10^2..10^6 times what the rest of a ray's life costs, and a ray's marches come
+// back at unrelated times.  A wave that owned its rays in registers (round 1) therefore ran its shading code
+// for whichever few lanes had a result (11 of 64 on C4).  Here nothing owns a ray:
+//   * every ray tree in flight is a CONTEXT, a 160-byte record in the workgroup's LDS pool (kPoolCtx of them:
+//     the current query, the Julia job and its result, the best hit so far or the shaded node, the sample id);
+//     the frames of its DFS stack are 48-byte records in HBM;
+//   * four rings of context ids in LDS connect the stages: READY_T (a trace query is complete or a context needs
+//     a new sample), READY_S (a shadow query is complete), MARCH (Julia jobs), NORMAL (converged marches);
+//   * SHADER waves pop up to 64 contexts of ONE kind, load them into lanes, and run collect -> resolve -> next
+//     query at full width (all lanes take the same branch of the shading code: wavefront compaction by kind);
+//     the new query's Julia job goes on MARCH, a query that met no Julia set straight back on a READY ring;
+//   * MARCHER waves pop jobs into all 64 lanes and march them (estimator iterations in blocks of four for the
+//     wave, march steps together once enough lanes wait for one), refilling a lane the moment its job ends;
+//     converged jobs are finished (6-tap normal, world-space hit) 64 at a time from the NORMAL ring.
+// One workgroup per CU; queues, contexts and results never leave LDS.
+constexpr int kPoolCtx = RT_JULIA_POOL;                       // contexts per workgroup
+constexpr int kCtxWords = 40;
+constexpr unsigned kJuliaQueueCap = 1024u;                    // a context is on at most one ring
+static_assert(kPoolCtx % 64 == 0 && kPoolCtx <= static_cast<int>(kJuliaQueueCap), "pool size");
+static_assert((kJuliaQueueCap & (kJuliaQueueCap - 1)) == 0, "ring size");
 #ifndef RT_JULIA_STEP_DIVISOR
 #define RT_JULIA_STEP_DIVISOR 2
 #endif
-#ifndef RT_JULIA_REFILL_MIN
-#define RT_JULIA_REFILL_MIN 1
+#ifndef RT_JULIA_SHADER_MIN_BATCH
+#define RT_JULIA_SHADER_MIN_BATCH 48       // a shader wave waits for this many ready contexts of one kind while the marchers have work
 #endif
-#ifndef RT_JULIA_TRACER_MIN_READY
-#define RT_JULIA_TRACER_MIN_READY 12        // a tracer wave waits for this many serviceable lanes while the marchers have work
-#endif
-constexpr unsigned kSpinLimit = 1u << 26;   // polling rounds before a wave declares the launch stuck
+constexpr unsigned long long kStuckTicks = 400000000ull;   // 4 s of the 100 MHz clock without any progress in the workgroup
 
-enum JobField : int { JF_PX = 0, JF_PY, JF_PZ, JF_DX, JF_DY, JF_DZ, JF_OX, JF_OY, JF_OZ, JF_JULIA, JF_STATUS, JF_COUNT };
+enum CtxWord : int {
+    CW_QO = 0, CW_QMAX = 3, CW_QD = 4, CW_FLAGS = 7,
+    CW_JP = 8, CW_JDIST = 11, CW_JD = 12, CW_JSTATUS = 15,   // job in: position, direction (object space); out: world point, distance, normal, status
+    CW_UNION = 16,                                           // 20 words: best hit so far (trace query) or the shaded node (shadow query)
+    CW_SLOT_LO = 36, CW_SLOT_HI = 37, CW_MISC = 38, CW_JIDX = 39
+};
+enum CtxFlag : unsigned { CF_KIND_MASK = 3u, CF_QACTIVE = 4u, CF_BLOCKED = 8u, CF_FOUND = 16u, CF_WAITING = 32u, CF_FRESH = 64u };
 enum JobStatus : unsigned { JOB_PENDING = 0u, JOB_MISS = 1u, JOB_HIT = 2u };
+enum RingId : int { R_MARCH = 0, R_NORMAL = 1, R_READY_T = 2, R_READY_S = 3, R_COUNT = 4 };
 
 struct JuliaRing {
-    unsigned ids[kJuliaQueueCap];           // owner id of entry i at [i & (cap-1)]
+    unsigned ids[kJuliaQueueCap];           // context id of entry i at [i & (cap-1)]
     unsigned ready[kJuliaQueueCap];         // == i+1 once entry i has been written
 };
-// running counts (never wrapped) of the two rings; entries head..tail-1 are reserved.  One 16-byte
-// record so that a marcher reads all four with a single LDS load.
-enum CtlWord : int { CTL_MARCH_HEAD = 0, CTL_MARCH_TAIL = 1, CTL_NORMAL_HEAD = 2, CTL_NORMAL_TAIL = 3 };
-struct JuliaShared {
-    __attribute__((aligned(16))) unsigned ctl[4];
-    unsigned tracers_done, abort, hungry, pad;
-    float job[JF_COUNT][kJuliaTracerLanes]; // SoA job records; results overwrite P (world point), D (world normal), OX (distance)
-    JuliaRing march, normal;
+struct PoolShared {
+    // running counts (never wrapped) of the rings: entries head..tail-1 of ring r are reserved, ctl[2r] = head, ctl[2r+1] = tail
+    __attribute__((aligned(16))) unsigned ctl[2 * R_COUNT];
+    unsigned dead;          // contexts that found the sample queue empty
+    unsigned abort;
+    unsigned heartbeat;     // bumped by every wave that made progress (watchdog)
+    unsigned pad;
+    JuliaRing ring[R_COUNT];
+    __attribute__((aligned(16))) float ctx[kPoolCtx][kCtxWords];
 };
+static_assert(sizeof(PoolShared) <= kJuliaStaticLdsBytes, "kJuliaStaticLdsBytes");
 
 RT_DEV unsigned lds_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 RT_DEV void lds_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-RT_DEV float lds_loadf(const float* p) { return __uint_as_float(lds_load(reinterpret_cast<const unsigned*>(p))); }
-RT_DEV void lds_storef(float* p, float v) { lds_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v)); }
 RT_DEV void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 RT_DEV void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
-// Lanes with `want` set append their owner id to the ring (one LDS atomic per wave).
+// Lanes with `want` set append their context id to the ring (one LDS atomic per wave).  Everything the lane wrote
+// to the context before the call is visible to whoever pops the entry.
 RT_DEV void ring_push(JuliaRing& q, unsigned* tail_word, bool want, unsigned id) {
     const unsigned long long mask = __ballot(want);
     if (mask == 0ull) return;
@@ -907,29 +933,142 @@ RT_DEV unsigned ring_pop(unsigned* head_word, const unsigned* tail_word, unsigne
     first = __shfl(h, 0);
     return got;
 }
-// Owner id of reserved entry i (waits for the producer's write; bounded).
+// Context id of reserved entry i (waits for the producer's write; bounded by the 100 MHz clock).
 RT_DEV unsigned ring_entry(JuliaRing& q, unsigned i, unsigned* abort_flag) {
-    unsigned spins = 0;
-    while (lds_load(&q.ready[i & (kJuliaQueueCap - 1)]) != i + 1u) {
-        if (++spins > kSpinLimit) {
-            lds_store(abort_flag, 1u);
-            return 0u;
+    if (lds_load(&q.ready[i & (kJuliaQueueCap - 1)]) != i + 1u) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (lds_load(&q.ready[i & (kJuliaQueueCap - 1)]) != i + 1u) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > kStuckTicks) {
+                lds_store(abort_flag, 1u);
+                return 0u;
+            }
         }
     }
     lds_acquire();
     return lds_load(&q.ids[i & (kJuliaQueueCap - 1)]);
 }
 
+// A wave that has nothing to do sleeps and watches the workgroup's heartbeat: the launch is given up only when no
+// wave of the workgroup has made progress for kStuckTicks (a march of 10 240 steps of 10 000 iterations is slow,
+// not stuck: its wave bumps the heartbeat with every block of march steps).
+struct IdleWatch {
+    unsigned seen;
+    unsigned long long since;
+    bool armed;
+};
+RT_DEV void idle_wait(PoolShared& sh, IdleWatch& w) {
+    __builtin_amdgcn_s_sleep(8);
+    const unsigned hb = lds_load(&sh.heartbeat);
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    if (!w.armed || hb != w.seen) {
+        w.armed = true;
+        w.seen = hb;
+        w.since = now;
+    } else if (now - w.since > kStuckTicks) {
+        lds_store(&sh.abort, 1u);
+    }
+}
+RT_DEV void beat(PoolShared& sh) {
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&sh.heartbeat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+typedef float F4 __attribute__((ext_vector_type(4)));
+RT_DEV F4 ctx_get(const float* c, int w) { return *reinterpret_cast<const F4*>(c + w); }
+RT_DEV void ctx_put(float* c, int w, F4 v) { *reinterpret_cast<F4*>(c + w) = v; }
+
+// Context -> lane.  `kind` is the ring's kind: the union words hold the best hit of a trace query or the node of a
+// shadow query.
+RT_DEV void ctx_load(const DevScene& sc, const float* c, Lane& L, bool& fresh, unsigned& jstatus, HitRec& jhit) {
+    const F4 a = ctx_get(c, CW_QO), b = ctx_get(c, CW_QD), jr0 = ctx_get(c, CW_JP), jr1 = ctx_get(c, CW_JD), t = ctx_get(c, CW_SLOT_LO);
+    const unsigned flags = __float_as_uint(b.w);
+    L.qo = v3(a.x, a.y, a.z);
+    L.qmax = a.w;
+    L.qd = v3(b.x, b.y, b.z);
+    L.qkind = static_cast<int>(flags & CF_KIND_MASK);
+    L.qactive = (flags & CF_QACTIVE) ? 1u : 0u;
+    L.blocked = (flags & CF_BLOCKED) ? 1u : 0u;
+    L.found = (flags & CF_FOUND) ? 1u : 0u;
+    L.state = (flags & CF_WAITING) ? S_WAIT : S_RESOLVE;
+    fresh = (flags & CF_FRESH) != 0u;
+    jhit.point = v3(jr0.x, jr0.y, jr0.z);
+    jhit.dist = jr0.w;
+    jhit.normal = v3(jr1.x, jr1.y, jr1.z);
+    jhit.uv = {0.0f, 0.0f};
+    jhit.ph = {0.0f, 0.0f};
+    jstatus = __float_as_uint(jr1.w);
+    L.out_slot = static_cast<unsigned long long>(__float_as_uint(t.x)) | (static_cast<unsigned long long>(__float_as_uint(t.y)) << 32);
+    const unsigned misc = __float_as_uint(t.z);
+    L.hue = static_cast<int>(misc & 15u) - 1;
+    L.sp = (misc >> 8) & 255u;
+    L.li = misc >> 16;
+    L.wavelength = L.hue >= 0 ? (static_cast<float>(L.hue) * 45.0f) / 180.0f - 1.0f : 0.0f;   // as start_sample
+    L.jidx = __float_as_uint(t.w);
+    const F4 u0 = ctx_get(c, CW_UNION), u1 = ctx_get(c, CW_UNION + 4), u2 = ctx_get(c, CW_UNION + 8), u3 = ctx_get(c, CW_UNION + 12), u4 = ctx_get(c, CW_UNION + 16);
+    if (L.qkind == Q_SHADOW) {
+        L.n_point = v3(u0.x, u0.y, u0.z);
+        L.n_cos = u0.w;
+        L.n_normal = v3(u1.x, u1.y, u1.z);
+        L.n_obj = __float_as_uint(u1.w);
+        L.n_dir = v3(u2.x, u2.y, u2.z);
+        L.n_ph = {u2.w, u3.w};
+        L.matcol[0] = u3.x; L.matcol[1] = u3.y; L.matcol[2] = u3.z;
+        L.acc[0] = u4.x; L.acc[1] = u4.y; L.acc[2] = u4.z;
+        L.best_tri = kNoTriangle;
+    } else {
+        L.best.dist = u0.x;
+        L.best_obj = __float_as_uint(u0.y);
+        L.best_cos = u0.z;
+        L.best_tri = __float_as_uint(u0.w);
+        L.best_u = u1.x;
+        L.best_v = u1.y;
+        L.best.uv = {u1.z, u1.w};
+        L.best.point = v3(u2.x, u2.y, u2.z);
+        L.best.normal = v3(u3.x, u3.y, u3.z);
+        L.best.ph = {u2.w, u3.w};
+    }
+    (void)sc;
+}
+// Lane -> context, for a lane whose new query is under way (waiting: a Julia job goes with it).
+RT_DEV void ctx_store(float* c, const Lane& L, bool waiting) {
+    unsigned flags = static_cast<unsigned>(L.qkind) & CF_KIND_MASK;
+    if (L.qactive) flags |= CF_QACTIVE;
+    if (L.blocked) flags |= CF_BLOCKED;
+    if (L.found) flags |= CF_FOUND;
+    if (waiting) flags |= CF_WAITING;
+    ctx_put(c, CW_QO, F4{L.qo.x, L.qo.y, L.qo.z, L.qmax});
+    ctx_put(c, CW_QD, F4{L.qd.x, L.qd.y, L.qd.z, __uint_as_float(flags)});
+    if (waiting) {
+        ctx_put(c, CW_JP, F4{L.jp.x, L.jp.y, L.jp.z, 0.0f});
+        ctx_put(c, CW_JD, F4{L.jd.x, L.jd.y, L.jd.z, __uint_as_float(JOB_PENDING)});
+    }
+    const unsigned misc = static_cast<unsigned>(L.hue + 1) | (L.sp << 8) | (L.li << 16);
+    ctx_put(c, CW_SLOT_LO, F4{__uint_as_float(static_cast<unsigned>(L.out_slot)), __uint_as_float(static_cast<unsigned>(L.out_slot >> 32)),
+                              __uint_as_float(misc), __uint_as_float(L.jidx)});
+    if (L.qkind == Q_SHADOW) {
+        ctx_put(c, CW_UNION, F4{L.n_point.x, L.n_point.y, L.n_point.z, L.n_cos});
+        ctx_put(c, CW_UNION + 4, F4{L.n_normal.x, L.n_normal.y, L.n_normal.z, __uint_as_float(L.n_obj)});
+        ctx_put(c, CW_UNION + 8, F4{L.n_dir.x, L.n_dir.y, L.n_dir.z, L.n_ph.x});
+        ctx_put(c, CW_UNION + 12, F4{L.matcol[0], L.matcol[1], L.matcol[2], L.n_ph.y});
+        ctx_put(c, CW_UNION + 16, F4{L.acc[0], L.acc[1], L.acc[2], 0.0f});
+    } else {
+        ctx_put(c, CW_UNION, F4{L.best.dist, __uint_as_float(L.best_obj), L.best_cos, __uint_as_float(L.best_tri)});
+        ctx_put(c, CW_UNION + 4, F4{L.best_u, L.best_v, L.best.uv.x, L.best.uv.y});
+        ctx_put(c, CW_UNION + 8, F4{L.best.point.x, L.best.point.y, L.best.point.z, L.best.ph.x});
+        ctx_put(c, CW_UNION + 12, F4{L.best.normal.x, L.best.normal.y, L.best.normal.z, L.best.ph.y});
+    }
+}
+
+// ---- marcher waves ------------------------------------------------------------------------------------------
 template <bool STATS>
-RT_DEV void julia_marcher(const DevScene& sc, JuliaShared& sh, Counters& n) {
+RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n) {
     const int lane = threadIdx.x & 63;
     bool has = false, busy = false;
-    unsigned owner = 0, jidx = 0, jstep = 0, it = 0;
+    unsigned owner = 0, jidx = 0, jstep = 0, it = 0, okind = 0;
     V3 p = {0, 0, 0}, d = {0, 0, 0};
     JuliaPk s = julia_pk_begin({0, 0, 0, 0});
     PkF2 cp = {0, 0}, cq = {0, 0};
     float cut = 0.0f;
-    unsigned idle_rounds = 0;
+    IdleWatch watch = {0u, 0ull, false};
     long long t_mark = STATS ? clock64() : 0;
     auto charge = [&](int slot) {
         if (STATS) {
@@ -946,39 +1085,40 @@ RT_DEV void julia_marcher(const DevScene& sc, JuliaShared& sh, Counters& n) {
         round++;
         if (n_has0 <= 56 || (round & 7u) == 0u) {
             typedef unsigned U4 __attribute__((ext_vector_type(4)));
-            typedef unsigned U2 __attribute__((ext_vector_type(2)));
-            const U4 ctl = *reinterpret_cast<volatile U4*>(sh.ctl);
-            const U2 flags = *reinterpret_cast<volatile U2*>(&sh.tracers_done);   // tracers_done, abort
+            const U4 ctl = *reinterpret_cast<volatile U4*>(sh.ctl);                  // march head, tail, normal head, tail
+            const U4 flags = *reinterpret_cast<volatile U4*>(&sh.dead);              // dead, abort, heartbeat
             if (flags.y != 0u) break;
             const unsigned n_conv = ctl.w - ctl.z, n_jobs = ctl.y - ctl.x;
             // ---- finish converged jobs: a full batch at once, a partial one when there is little else to do
             if (n_conv >= 64u || (n_conv > 0u && n_has0 < 32 && n_jobs == 0u)) {
                 unsigned first = 0;
-                const unsigned got = ring_pop(&sh.ctl[CTL_NORMAL_HEAD], &sh.ctl[CTL_NORMAL_TAIL], 64u, first);
+                const unsigned got = ring_pop(&sh.ctl[2 * R_NORMAL], &sh.ctl[2 * R_NORMAL + 1], 64u, first);
+                bool to_t = false, to_s = false;
+                unsigned o = 0;
                 if (static_cast<unsigned>(lane) < got) {
-                    const unsigned o = ring_entry(sh.normal, first + lane, &sh.abort);
-                    const DevJulia& j = sc.julias[__float_as_uint(lds_loadf(&sh.job[JF_JULIA][o]))];
-                    const V3 jp = v3(lds_loadf(&sh.job[JF_PX][o]), lds_loadf(&sh.job[JF_PY][o]), lds_loadf(&sh.job[JF_PZ][o]));
-                    const V3 jd = v3(lds_loadf(&sh.job[JF_DX][o]), lds_loadf(&sh.job[JF_DY][o]), lds_loadf(&sh.job[JF_DZ][o]));
-                    const V3 ow = v3(lds_loadf(&sh.job[JF_OX][o]), lds_loadf(&sh.job[JF_OY][o]), lds_loadf(&sh.job[JF_OZ][o]));
+                    o = ring_entry(sh.ring[R_NORMAL], first + lane, &sh.abort);
+                    float* c = sh.ctx[o];
+                    const F4 q0 = ctx_get(c, CW_QO), q1 = ctx_get(c, CW_QD), j0 = ctx_get(c, CW_JP), j1 = ctx_get(c, CW_JD);
+                    const DevJulia& j = sc.julias[__float_as_uint(c[CW_JIDX])];
                     bump<STATS>(n, C_JULIA_NORMALS);
                     unsigned long long iters = 0;
                     HitRec h;
-                    // the distance limits of src/objects.cpp:236 are applied by the owner (it knows the query)
-                    const bool hit = julia_finish<STATS>(j, ow, jp, jd, kInfinite, h, iters);
+                    // the distance limits of src/objects.cpp:236 are applied by the shader wave (it knows the query)
+                    const bool hit = julia_finish<STATS>(j, v3(q0.x, q0.y, q0.z), v3(j0.x, j0.y, j0.z), v3(j1.x, j1.y, j1.z), kInfinite, h, iters);
                     bump<STATS>(n, C_JULIA_DE_ITERATIONS, iters);
                     if (hit) {
-                        lds_storef(&sh.job[JF_PX][o], h.point.x);
-                        lds_storef(&sh.job[JF_PY][o], h.point.y);
-                        lds_storef(&sh.job[JF_PZ][o], h.point.z);
-                        lds_storef(&sh.job[JF_DX][o], h.normal.x);
-                        lds_storef(&sh.job[JF_DY][o], h.normal.y);
-                        lds_storef(&sh.job[JF_DZ][o], h.normal.z);
-                        lds_storef(&sh.job[JF_OX][o], h.dist);
+                        ctx_put(c, CW_JP, F4{h.point.x, h.point.y, h.point.z, h.dist});
+                        ctx_put(c, CW_JD, F4{h.normal.x, h.normal.y, h.normal.z, __uint_as_float(JOB_HIT)});
+                    } else {
+                        c[CW_JSTATUS] = __uint_as_float(JOB_MISS);
                     }
-                    lds_release();
-                    lds_storef(&sh.job[JF_STATUS][o], __uint_as_float(hit ? JOB_HIT : JOB_MISS));
+                    const bool shadow = (__float_as_uint(q1.w) & CF_KIND_MASK) == static_cast<unsigned>(Q_SHADOW);
+                    to_s = shadow;
+                    to_t = !shadow;
                 }
+                ring_push(sh.ring[R_READY_T], &sh.ctl[2 * R_READY_T + 1], to_t, o);
+                ring_push(sh.ring[R_READY_S], &sh.ctl[2 * R_READY_S + 1], to_s, o);
+                beat(sh);
                 if (STATS && lane == 0) n.v[D_NORMAL_PHASES]++;
                 if (STATS && static_cast<unsigned>(lane) < got) n.v[D_NORMAL_LANES]++;
                 charge(D_NORMAL_CYCLES);
@@ -988,13 +1128,16 @@ RT_DEV void julia_marcher(const DevScene& sc, JuliaShared& sh, Counters& n) {
             const unsigned long long need = __ballot(!has);
             if (need != 0ull && n_jobs != 0u) {
                 unsigned first = 0;
-                const unsigned got = ring_pop(&sh.ctl[CTL_MARCH_HEAD], &sh.ctl[CTL_MARCH_TAIL], static_cast<unsigned>(__popcll(need)), first);
+                const unsigned got = ring_pop(&sh.ctl[2 * R_MARCH], &sh.ctl[2 * R_MARCH + 1], static_cast<unsigned>(__popcll(need)), first);
                 const unsigned rank = __popcll(need & ((1ull << lane) - 1ull));
                 if (!has && rank < got) {
-                    owner = ring_entry(sh.march, first + rank, &sh.abort);
-                    jidx = __float_as_uint(lds_loadf(&sh.job[JF_JULIA][owner]));
-                    p = v3(lds_loadf(&sh.job[JF_PX][owner]), lds_loadf(&sh.job[JF_PY][owner]), lds_loadf(&sh.job[JF_PZ][owner]));
-                    d = v3(lds_loadf(&sh.job[JF_DX][owner]), lds_loadf(&sh.job[JF_DY][owner]), lds_loadf(&sh.job[JF_DZ][owner]));
+                    owner = ring_entry(sh.ring[R_MARCH], first + rank, &sh.abort);
+                    const float* c = sh.ctx[owner];
+                    const F4 j0 = ctx_get(c, CW_JP), j1 = ctx_get(c, CW_JD);
+                    jidx = __float_as_uint(c[CW_JIDX]);
+                    okind = __float_as_uint(c[CW_FLAGS]) & CF_KIND_MASK;
+                    p = v3(j0.x, j0.y, j0.z);
+                    d = v3(j1.x, j1.y, j1.z);
                     const DevJulia& j = sc.julias[jidx];
                     cp = {j.c[0], j.c[1]};
                     cq = {j.c[2], j.c[3]};
@@ -1006,22 +1149,16 @@ RT_DEV void julia_marcher(const DevScene& sc, JuliaShared& sh, Counters& n) {
                     busy = true;
                 }
             }
-            // tell the tracers whether this wave runs short of jobs (they then stop waiting for full phases)
             const int n_now = __popcll(__ballot(has));
-            if (lane == 0) {
-                const unsigned hungry = n_now < 40 ? 1u : 0u;
-                if (lds_load(&sh.hungry) != hungry) lds_store(&sh.hungry, hungry);
-            }
             if (n_now == 0) {
-                if (flags.x >= static_cast<unsigned>(kJuliaWaves - kJuliaMarcherWaves) && n_jobs == 0u && n_conv == 0u) break;
-                __builtin_amdgcn_s_sleep(8);
-                if (++idle_rounds > kSpinLimit) lds_store(&sh.abort, 1u);
+                if (flags.x >= static_cast<unsigned>(kPoolCtx)) break;     // every context is dead: no job can come any more
+                idle_wait(sh, watch);
                 charge(D_M_IDLE_CYCLES);
                 continue;
             }
         }
         const int n_has = __popcll(__ballot(has));
-        idle_rounds = 0;
+        watch.armed = false;
         charge(D_M_REFILL_CYCLES);
         if (STATS && lane == 0) n.v[D_MARCH_PHASES]++;
         if (STATS && has) n.v[D_MARCH_LANES]++;
@@ -1043,7 +1180,7 @@ RT_DEV void julia_marcher(const DevScene& sc, JuliaShared& sh, Counters& n) {
         if (STATS && lane == 0) n.v[D_M_TAIL_BLOCKS]++;
         if (STATS && has && !busy) n.v[D_M_TAIL_LANES]++;
         // ---- march steps of the lanes whose estimate is complete (src/objects.cpp:206-221)
-        bool converged = false;
+        bool converged = false, miss_t = false, miss_s = false;
         if (has && !busy) {
             bump<STATS>(n, C_JULIA_STEPS);
             const int r = julia_advance(julia_distance_tail_auto(s.m2, s.d2), p, d, jstep);
@@ -1053,167 +1190,135 @@ RT_DEV void julia_marcher(const DevScene& sc, JuliaShared& sh, Counters& n) {
                 busy = true;
             } else {
                 has = false;
+                float* c = sh.ctx[owner];
                 if (r == 1) {
                     converged = true;
-                    lds_storef(&sh.job[JF_PX][owner], p.x);
-                    lds_storef(&sh.job[JF_PY][owner], p.y);
-                    lds_storef(&sh.job[JF_PZ][owner], p.z);
+                    c[CW_JP] = p.x;
+                    c[CW_JP + 1] = p.y;
+                    c[CW_JP + 2] = p.z;
                 } else {
-                    lds_storef(&sh.job[JF_STATUS][owner], __uint_as_float(JOB_MISS));
+                    c[CW_JSTATUS] = __uint_as_float(JOB_MISS);
+                    miss_s = okind == static_cast<unsigned>(Q_SHADOW);
+                    miss_t = !miss_s;
                 }
             }
         }
-        ring_push(sh.normal, &sh.ctl[CTL_NORMAL_TAIL], converged, owner);
+        ring_push(sh.ring[R_NORMAL], &sh.ctl[2 * R_NORMAL + 1], converged, owner);
+        ring_push(sh.ring[R_READY_T], &sh.ctl[2 * R_READY_T + 1], miss_t, owner);
+        ring_push(sh.ring[R_READY_S], &sh.ctl[2 * R_READY_S + 1], miss_s, owner);
+        beat(sh);
         charge(D_M_TAIL_CYCLES);
     }
 }
 
+// ---- shader waves -------------------------------------------------------------------------------------------
 template <bool STATS>
-__global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia_kernel(const DevScene sc_global, const DevJob job) {
-    extern __shared__ __align__(16) unsigned char lds_blob[];
-    __shared__ JuliaShared sh;
-    const DevScene& sc = sc_global;
-    const unsigned char* table_base = sc.shade_blob;
-    for (unsigned i = threadIdx.x; i < kJuliaQueueCap; i += blockDim.x) {
-        sh.march.ready[i] = 0u;
-        sh.normal.ready[i] = 0u;
-    }
-    if (threadIdx.x == 0) {
-        sh.ctl[0] = sh.ctl[1] = sh.ctl[2] = sh.ctl[3] = 0u;
-        sh.tracers_done = 0u;
-        sh.abort = (job.debug_abort != 0u && blockIdx.x == 0) ? 1u : 0u;   // RT_OPT_DEBUG_FORCE_ABORT
-        sh.hungry = 1u;
-        sh.pad = 0u;
-    }
-    if (sc.shade_blob_in_lds) {
-        for (unsigned i = threadIdx.x * 16u; i < sc.shade_blob_bytes; i += blockDim.x * 16u) {
-            *reinterpret_cast<uint4*>(lds_blob + i) = *reinterpret_cast<const uint4*>(sc.shade_blob + i);
-        }
-        table_base = lds_blob;
-    }
-    __syncthreads();
-    const ShadeTables T = tables_of(sc, table_base);
-    Counters n;
-    if (STATS) for (int i = 0; i < C_COUNT; i++) n.v[i] = 0;
-    const int wave = threadIdx.x >> 6;
-    if (wave < kJuliaMarcherWaves) {
-        julia_marcher<STATS>(sc, sh, n);
-        if (lds_load(&sh.abort) != 0u && (threadIdx.x & 63) == 0) atomicExch(job.queue_head + 1, 1ull);
-        flush_counters<STATS>(n, job.counters);
-        return;
-    }
-
-    // ---- tracer waves ---------------------------------------------------------------------------------
-    const unsigned owner = threadIdx.x - kJuliaMarcherWaves * 64;
-    const unsigned long long grid_lanes = static_cast<unsigned long long>(gridDim.x) * kJuliaTracerLanes;
-    const unsigned long long gid = static_cast<unsigned long long>(blockIdx.x) * kJuliaTracerLanes + owner;
-    const FrameRef stack = {job.stack + gid, grid_lanes};
-    Lane L;
-    __shared__ float top_store[kFrameFields * kJuliaTracerLanes];
-    L.top_base = top_store + owner;
-    L.top_stride = kJuliaTracerLanes;
-    L.state = S_RESOLVE;       // "resolve" of a lane without a sample = fetch one
-    L.qkind = -1;
-    L.sp = 0;
-    L.jidx = 0;
-    L.jstep = 0;
-    bool fresh = true;
-    bool want = false;
-    WaveIds wave_ids = wave_ids_begin(gid, job.n_waves, job.static_blocks);
-    unsigned wait_rounds = 0;
+RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob& job, PoolShared& sh, Counters& n, WaveIds& wave_ids) {
+    const int lane = threadIdx.x & 63;
+    IdleWatch watch = {0u, 0ull, false};
+    unsigned patience = 0;
     long long t_mark = STATS ? clock64() : 0;
     auto charge = [&](int slot) {
         if (STATS) {
             const long long now = clock64();
-            if ((threadIdx.x & 63) == 0) n.v[slot] += static_cast<unsigned long long>(now - t_mark);
+            if (lane == 0) n.v[slot] += static_cast<unsigned long long>(now - t_mark);
             t_mark = now;
         }
     };
+    float* const wg_frames = job.stack + static_cast<size_t>(blockIdx.x) * kPoolCtx * (sc.max_bounces + 1) * kFrameRecordWords;
     for (;;) {
-        if (lds_load(&sh.abort) != 0u) break;
-        // ---- collect finished jobs (Julia::intersect's last checks and the acceptance rule)
-        bool push = false;
-        if (L.state == S_WAIT) {
-            const unsigned st = __float_as_uint(lds_loadf(&sh.job[JF_STATUS][owner]));
-            if (st != JOB_PENDING) {
-                lds_acquire();
-                const DevJulia& j = sc.julias[L.jidx];
-                if (st == JOB_HIT) {
-                    HitRec h;
-                    h.dist = lds_loadf(&sh.job[JF_OX][owner]);
-                    h.point = v3(lds_loadf(&sh.job[JF_PX][owner]), lds_loadf(&sh.job[JF_PY][owner]), lds_loadf(&sh.job[JF_PZ][owner]));
-                    h.normal = v3(lds_loadf(&sh.job[JF_DX][owner]), lds_loadf(&sh.job[JF_DY][owner]), lds_loadf(&sh.job[JF_DZ][owner]));
-                    h.uv = {0.0f, 0.0f};
-                    h.ph = {0.0f, 0.0f};
-                    // Julia::intersect ignores max_distance until this final check (src/objects.cpp:236)
-                    const float limit = L.qkind == Q_SHADOW ? L.qmax : kInfinite;
-                    if (!(h.dist > limit)) accept_julia_hit(L, h, j, T.materials[j.material]);
-                }
-                L.state = S_RESOLVE;
-                if (L.qactive) {
-                    // next Julia set of the scene, if any
-                    for (unsigned k = L.jidx + 1; k < sc.n_julias; k++) {
-                        bump<STATS>(n, C_JULIA_QUERIES);
-                        if (julia_enter(sc.julias[k], L.qo, L.qd, L.jp, L.jd)) {
-                            L.jidx = k;
-                            L.state = S_WAIT;
-                            push = true;
-                            break;
-                        }
+        typedef unsigned U4 __attribute__((ext_vector_type(4)));
+        const U4 ctl_m = *reinterpret_cast<volatile U4*>(sh.ctl);             // march head, tail, normal head, tail
+        const U4 ctl_r = *reinterpret_cast<volatile U4*>(sh.ctl + 4);         // ready_t head, tail, ready_s head, tail
+        const U4 flags = *reinterpret_cast<volatile U4*>(&sh.dead);           // dead, abort, heartbeat
+        if (flags.y != 0u || flags.x >= static_cast<unsigned>(kPoolCtx)) break;
+        const unsigned n_t = ctl_r.y - ctl_r.x, n_s = ctl_r.w - ctl_r.z, n_jobs = ctl_m.y - ctl_m.x;
+        const int r = n_t >= n_s ? R_READY_T : R_READY_S;
+        const unsigned n_ready = n_t >= n_s ? n_t : n_s;
+        // a full batch at once; a partial one when the marchers are about to run out of jobs, or after a while
+        if (n_ready == 0u || (n_ready < static_cast<unsigned>(RT_JULIA_SHADER_MIN_BATCH) && n_jobs >= 64u && patience < 16u)) {
+            if (n_ready == 0u) idle_wait(sh, watch); else __builtin_amdgcn_s_sleep(4);
+            patience++;
+            charge(D_T_WAIT_CYCLES);
+            continue;
+        }
+        unsigned first = 0;
+        const unsigned got = ring_pop(&sh.ctl[2 * r], &sh.ctl[2 * r + 1], 64u, first);
+        if (got == 0u) continue;
+        patience = 0;
+        watch.armed = false;
+        const bool mine = static_cast<unsigned>(lane) < got;
+        Lane L;
+        L.state = S_IDLE;
+        L.qkind = -1;
+        L.sp = 0;
+        L.jidx = 0;
+        L.jstep = 0;
+        L.qactive = 0u;
+        unsigned id = 0, jstatus = JOB_PENDING;
+        bool fresh = false;
+        HitRec jhit = {};
+        if (mine) {
+            id = ring_entry(sh.ring[r], first + lane, &sh.abort);
+            ctx_load(sc, sh.ctx[id], L, fresh, jstatus, jhit);
+        }
+        if (STATS) {
+            if (lane == 0) n.v[D_RESOLVE_PHASES]++;
+            if (mine) n.v[D_RESOLVE_LANES]++;
+        }
+        // ---- a finished Julia job: Julia::intersect's last checks and the acceptance rule; then the scene's next set
+        bool push_job = false;
+        if (mine && L.state == S_WAIT) {
+            const DevJulia& j = sc.julias[L.jidx];
+            if (jstatus == JOB_HIT) {
+                // Julia::intersect ignores max_distance until this final check (src/objects.cpp:236)
+                const float limit = L.qkind == Q_SHADOW ? L.qmax : kInfinite;
+                if (!(jhit.dist > limit)) accept_julia_hit(L, jhit, j, T.materials[j.material]);
+            }
+            L.state = S_RESOLVE;
+            if (L.qactive) {
+                for (unsigned k = L.jidx + 1; k < sc.n_julias; k++) {
+                    bump<STATS>(n, C_JULIA_QUERIES);
+                    if (julia_enter(sc.julias[k], L.qo, L.qd, L.jp, L.jd)) {
+                        L.jidx = k;
+                        L.state = S_WAIT;
+                        push_job = true;
+                        break;
                     }
                 }
             }
         }
-        const int n_query = __popcll(__ballot(L.state == S_QUERY));
-        const int n_resolve = __popcll(__ballot(L.state == S_RESOLVE));
-        const int n_wait = __popcll(__ballot(L.state == S_WAIT));
-        int phase = 0;
-        if (n_query + n_resolve == 0) {
-            if (n_wait == 0) break;
-        } else if (n_wait == 0 || n_query + n_resolve >= RT_JULIA_TRACER_MIN_READY || lds_load(&sh.hungry) != 0u || wait_rounds > 64u) {
-            phase = RT_JULIA_FUSE_QUERY ? (n_resolve > 0 ? S_RESOLVE : S_QUERY) : (n_query >= n_resolve ? S_QUERY : S_RESOLVE);
-        }
-        if (phase == S_RESOLVE) {
-            const bool mine = L.state == S_RESOLVE;
-            if (STATS) {
-                if ((threadIdx.x & 63) == 0) n.v[D_RESOLVE_PHASES]++;
-                if (mine) n.v[D_RESOLVE_LANES]++;
-            }
-            bool done = false;
-            Col value = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (mine && !fresh) resolve_lane<STATS>(sc, T, job, stack, L, n, done, value);
-            if (mine && done) store_sample(sc, job, L, value);
-            if (mine && (fresh || done)) {
-                L.state = S_IDLE;
-                want = true;
-            }
-            const int n_want = __popcll(__ballot(want));
-            const int n_live = __popcll(__ballot(L.state == S_QUERY || L.state == S_WAIT));
-            bool need = want && (n_want >= RT_JULIA_REFILL_MIN || n_live == 0);
-            if (need) want = false;
-            while (__any(need)) {
-                unsigned long long id = 0;
-                const bool got = fetch_ids(job.queue_head, job.dyn_base, job.n_samples, job.id_chunk, wave_ids, need, id);
-                if (need) {
-                    if (!got) {
-                        need = false;
-                    } else if (start_sample(sc, job, id, L)) {
-                        need = false;
-                        fresh = false;
-                    }
+        // ---- resolve: one step of the ray tree; a finished sample is stored and the context takes the next one
+        bool done = false;
+        Col value = {0.0f, 0.0f, 0.0f, 0.0f};
+        const FramesInHbm frames = {wg_frames + static_cast<size_t>(id) * (sc.max_bounces + 1) * kFrameRecordWords};
+        if (mine && L.state == S_RESOLVE && !fresh) resolve_lane<STATS>(sc, T, job, frames, L, n, done, value);
+        if (mine && done) store_sample(sc, job, L, value);
+        bool need = mine && (fresh || done);
+        bool died = false;
+        while (__any(need)) {
+            unsigned long long sid = 0;
+            const bool got_id = fetch_ids(job.queue_head, job.dyn_base, job.n_samples, job.id_chunk, wave_ids, need, sid);
+            if (need) {
+                if (!got_id) {
+                    need = false;       // the queue is exhausted: this context is done for the launch
+                    died = true;
+                    L.state = S_IDLE;
+                } else if (start_sample(sc, job, sid, L)) {
+                    need = false;
                 }
             }
         }
-        // A resolve leaves its lanes with their next query: it runs in the same pass (RT_JULIA_FUSE_QUERY), so a
-        // ray costs the tracer one pass, not two, and reaches the marchers a pass earlier.
-        if (phase == S_QUERY || (RT_JULIA_FUSE_QUERY && phase == S_RESOLVE && __any(L.state == S_QUERY))) {
-            const bool mine = L.state == S_QUERY;
+        charge(D_RESOLVE_CYCLES);
+        // ---- the new query against everything that is not a Julia set, then the first set it enters
+        if (__any(L.state == S_QUERY)) {
+            const bool q = L.state == S_QUERY;
             if (STATS) {
-                if ((threadIdx.x & 63) == 0) n.v[D_QUERY_PHASES]++;
-                if (mine) n.v[D_QUERY_LANES]++;
+                if (lane == 0) n.v[D_QUERY_PHASES]++;
+                if (q) n.v[D_QUERY_LANES]++;
             }
-            query_objects<STATS>(sc, L, mine, n);
-            if (mine) {
+            query_objects<STATS>(sc, L, q, n);
+            if (q) {
                 L.state = S_RESOLVE;
                 if (L.qactive) {
                     for (unsigned k = 0; k < sc.n_julias; k++) {
@@ -1221,42 +1326,60 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
                         if (julia_enter(sc.julias[k], L.qo, L.qd, L.jp, L.jd)) {
                             L.jidx = k;
                             L.state = S_WAIT;
-                            push = true;
+                            push_job = true;
                             break;
                         }
                     }
                 }
             }
         }
-        // ---- hand new jobs to the marchers
-        if (push) {
-            lds_storef(&sh.job[JF_PX][owner], L.jp.x);
-            lds_storef(&sh.job[JF_PY][owner], L.jp.y);
-            lds_storef(&sh.job[JF_PZ][owner], L.jp.z);
-            lds_storef(&sh.job[JF_DX][owner], L.jd.x);
-            lds_storef(&sh.job[JF_DY][owner], L.jd.y);
-            lds_storef(&sh.job[JF_DZ][owner], L.jd.z);
-            lds_storef(&sh.job[JF_OX][owner], L.qo.x);
-            lds_storef(&sh.job[JF_OY][owner], L.qo.y);
-            lds_storef(&sh.job[JF_OZ][owner], L.qo.z);
-            lds_storef(&sh.job[JF_JULIA][owner], __uint_as_float(L.jidx));
-            lds_storef(&sh.job[JF_STATUS][owner], __uint_as_float(JOB_PENDING));
-        }
-        ring_push(sh.march, &sh.ctl[CTL_MARCH_TAIL], push, owner);
-        charge(phase == S_QUERY ? D_QUERY_CYCLES : phase == S_RESOLVE ? D_RESOLVE_CYCLES : D_T_WAIT_CYCLES);
-        if (phase == 0) {
-            __builtin_amdgcn_s_sleep(8);
-            wait_rounds++;
-            if (wait_rounds > kSpinLimit) lds_store(&sh.abort, 1u);
-        } else {
-            wait_rounds = 0;
+        // ---- back into the pool, and on to the next ring
+        const bool alive = mine && !died;
+        if (alive) ctx_store(sh.ctx[id], L, push_job);
+        ring_push(sh.ring[R_MARCH], &sh.ctl[2 * R_MARCH + 1], alive && push_job, id);
+        ring_push(sh.ring[R_READY_T], &sh.ctl[2 * R_READY_T + 1], alive && !push_job && L.qkind != Q_SHADOW, id);
+        ring_push(sh.ring[R_READY_S], &sh.ctl[2 * R_READY_S + 1], alive && !push_job && L.qkind == Q_SHADOW, id);
+        const unsigned n_died = static_cast<unsigned>(__popcll(__ballot(died)));
+        if (n_died != 0u && lane == 0) __hip_atomic_fetch_add(&sh.dead, n_died, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        beat(sh);
+        charge(D_QUERY_CYCLES);
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia_kernel(const DevScene sc_global, const DevJob job) {
+    __shared__ PoolShared sh;
+    const DevScene& sc = sc_global;
+    for (unsigned i = threadIdx.x; i < kJuliaQueueCap; i += blockDim.x) {
+        for (int r = 0; r < R_COUNT; r++) sh.ring[r].ready[i] = 0u;
+        // every context starts on READY_T, asking for its first sample
+        if (i < static_cast<unsigned>(kPoolCtx)) {
+            sh.ring[R_READY_T].ids[i] = i;
+            sh.ring[R_READY_T].ready[i] = i + 1u;
+            sh.ctx[i][CW_FLAGS] = __uint_as_float(CF_FRESH);
         }
     }
-    if ((threadIdx.x & 63) == 0) {
-        lds_release();
-        __hip_atomic_fetch_add(&sh.tracers_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (lds_load(&sh.abort) != 0u) atomicExch(job.queue_head + 1, 1ull);
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < 2 * R_COUNT; w++) sh.ctl[w] = 0u;
+        sh.ctl[2 * R_READY_T + 1] = static_cast<unsigned>(kPoolCtx);
+        sh.dead = 0u;
+        sh.abort = (job.debug_abort != 0u && blockIdx.x == 0) ? 1u : 0u;   // RT_OPT_DEBUG_FORCE_ABORT
+        sh.heartbeat = 0u;
+        sh.pad = 0u;
     }
+    __syncthreads();
+    const ShadeTables T = tables_of(sc, sc.shade_blob);
+    Counters n;
+    if (STATS) for (int i = 0; i < C_COUNT; i++) n.v[i] = 0;
+    const int wave = threadIdx.x >> 6;
+    if (wave < kJuliaMarcherWaves) {
+        julia_marcher<STATS>(sc, sh, n);
+    } else {
+        const unsigned shader_wave = blockIdx.x * (kJuliaWaves - kJuliaMarcherWaves) + (wave - kJuliaMarcherWaves);
+        WaveIds wave_ids = wave_ids_begin(static_cast<unsigned long long>(shader_wave) << 6, job.n_waves, job.static_blocks);
+        julia_shader<STATS>(sc, T, job, sh, n, wave_ids);
+    }
+    if (lds_load(&sh.abort) != 0u && (threadIdx.x & 63) == 0) atomicExch(job.queue_head + 1, 1ull);
     flush_counters<STATS>(n, job.counters);
 }
 

@@ -201,17 +201,18 @@ constexpr uint32_t kDepositLongRun = 32;    // deposits into one texel from whic
 
 // Shape of trace_julia_kernel's workgroup (rt_kernels.hip), shared with the launch code
 #ifndef RT_JULIA_WAVES
-#define RT_JULIA_WAVES 16
+#define RT_JULIA_WAVES 12
 #endif
 #ifndef RT_JULIA_MARCHERS
-#define RT_JULIA_MARCHERS 7
+#define RT_JULIA_MARCHERS 8
+#endif
+#ifndef RT_JULIA_POOL
+#define RT_JULIA_POOL 768
 #endif
 constexpr int kJuliaWaves = RT_JULIA_WAVES;              // per workgroup, a multiple of 4 (waves per SIMD = kJuliaWaves / 4)
-constexpr int kJuliaMarcherWaves = RT_JULIA_MARCHERS;
-#ifndef RT_JULIA_STATIC_LDS_KB
-#define RT_JULIA_STATIC_LDS_KB 68
-#endif
-constexpr uint32_t kJuliaStaticLdsBytes = RT_JULIA_STATIC_LDS_KB * 1024;     // upper bound of its static LDS (job table + rings)
+constexpr int kJuliaMarcherWaves = RT_JULIA_MARCHERS;    // the rest are shader waves
+constexpr int kJuliaPoolContexts = RT_JULIA_POOL;        // ray contexts per workgroup (LDS pool)
+constexpr uint32_t kJuliaStaticLdsBytes = 160 * 1024;    // its static LDS (pool + rings) may take the whole CU's
 
 enum CounterSlot : int {
     C_PRIMARY = 0, C_SECONDARY, C_SHADOW, C_PHOTON_SEGMENTS, C_PHOTON_DEPOSITS, C_SPHERE_TESTS, C_TRIANGLE_TESTS,
