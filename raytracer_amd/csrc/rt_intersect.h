@@ -214,6 +214,27 @@ RT_DEV bool julia_pk_iterate(JuliaPk& s, PkF2 cp, PkF2 cq) {
     julia_pk_squares(s);
     return s.m2 > 1e10f || s.d2 == __builtin_inff();
 }
+// One pass without the exit test (the marcher waves test m2 themselves and look at d2 once per block of four).
+RT_DEV void julia_pk_iterate_only(JuliaPk& s, PkF2 cp, PkF2 cq) {
+    s.d2 *= 4.0f * s.m2;
+    PkF2 rq, aq, xb, yc, t, n;
+    asm volatile(
+        "v_pk_mul_f32 %0, %6, %7 op_sel:[0,0] op_sel_hi:[0,1]\n\t"   // (rb, rc)
+        "v_pk_mul_f32 %1, %6, %7 op_sel:[1,0] op_sel_hi:[1,1]\n\t"   // (ab, ac)
+        "v_pk_mul_f32 %2, %6, %7 op_sel:[0,0] op_sel_hi:[1,0]\n\t"   // (rb, ab)
+        "v_pk_mul_f32 %3, %6, %7 op_sel:[1,1] op_sel_hi:[0,1]\n\t"   // (ac, rc)
+        "v_pk_add_f32 %4, %8, %9 neg_lo:[0,1]\n\t"                    // (rr - aa, ra + ar)
+        "v_pk_add_f32 %5, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"   // (rb - ac, rc + ab)
+        "v_pk_add_f32 %4, %4, %10 neg_lo:[0,1]\n\t"                   // (.. - bb, .. + bc)
+        "v_pk_add_f32 %5, %5, %2 neg_hi:[0,1]\n\t"                    // (.. + br, .. - ba)
+        "v_pk_add_f32 %4, %4, %11 neg_lo:[0,1] neg_hi:[0,1]\n\t"      // (.. - cc, .. - cb)
+        "v_pk_add_f32 %5, %5, %3"                                      // (.. + ca, .. + cr)
+        : "=&v"(rq), "=&v"(aq), "=&v"(xb), "=&v"(yc), "=&v"(t), "=&v"(n)
+        : "v"(s.p), "v"(s.q), "v"(s.u), "v"(s.v), "v"(s.w), "v"(s.x));
+    s.p = t + cp;
+    s.q = n + cq;
+    julia_pk_squares(s);
+}
 // sqrt(m2/d2)*0.5f*log(sqrt(m2)): float division, everything else in double (Y8)
 RT_DEV float julia_distance_tail(float m2, float d2) {
     const double tail = sqrt(static_cast<double>(m2 / d2)) * 0.5 * log(sqrt(static_cast<double>(m2)));
@@ -289,10 +310,76 @@ RT_DEV bool julia_distance_tail_fast(float m2, float d2, float& out) {
     out = f;
     return true;
 }
+// The march's own tail: the estimator left by escape (m2 > 1e10, so ln(sqrt(m2)) is far from zero).  There
+// ln(S) with S = sqrt((double)m2) rounded equals 0.5*ln(m2) to 2^-53, so E = sqrt(q)*0.25*ln(m2) needs neither the
+// double square root of m2 nor a double frexp: exponent and mantissa come from the float itself.  Same decision
+// rule as julia_distance_tail_fast (the float is returned only when E is clear of every rounding boundary by 2^-44
+// of its value); everything else, and every operand outside m2 in [16, 1e30), goes to that function.
+// Model and sweep against the reference's expression: tools/fast_tail_model.c (lean), tests/test_fast_tail_model.py.
+RT_DEV bool julia_distance_tail_lean(float m2, float d2, float& out) {
+    if (!(m2 >= 16.0f && m2 < 1e30f)) return false;
+    const float q = m2 / d2;
+    if (!(q >= 1e-30f && q < 1e30f)) return false;
+    const double x = static_cast<double>(q);
+    double g;
+    {
+        const double y = static_cast<double>(__builtin_amdgcn_rsqf(q));
+        g = x * y;
+        double h = 0.5 * y;
+        double r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+        r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);   // sqrt(q)
+    }
+    int e;
+    float mf = __builtin_frexpf(m2, &e);   // [0.5, 1), exact
+    if (mf < 0.70710678f) {
+        mf *= 2.0f;
+        e -= 1;
+    }
+    const double m = static_cast<double>(mf);
+    const double num = m - 1.0, den = m + 1.0;
+    double ry = static_cast<double>(__builtin_amdgcn_rcpf(static_cast<float>(den)));
+    double er = __builtin_fma(-den, ry, 1.0);
+    ry = __builtin_fma(ry, er, ry);
+    er = __builtin_fma(-den, ry, 1.0);
+    ry = __builtin_fma(ry, er, ry);
+    const double s = num * ry;
+    const double s2 = s * s;
+    double p = 1.0 / 19.0;
+    p = __builtin_fma(p, s2, 1.0 / 17.0);
+    p = __builtin_fma(p, s2, 1.0 / 15.0);
+    p = __builtin_fma(p, s2, 1.0 / 13.0);
+    p = __builtin_fma(p, s2, 1.0 / 11.0);
+    p = __builtin_fma(p, s2, 1.0 / 9.0);
+    p = __builtin_fma(p, s2, 1.0 / 7.0);
+    p = __builtin_fma(p, s2, 1.0 / 5.0);
+    p = __builtin_fma(p, s2, 1.0 / 3.0);
+    p = p * s2;
+    const double lnm = 2.0 * __builtin_fma(s, p, s);
+    const double ln = __builtin_fma(static_cast<double>(e), 0.69314718055994530942, lnm);   // ln(m2)
+    const double big = g * 0.25 * ln;
+    const float f = static_cast<float>(big);
+    const unsigned bits = __float_as_uint(f);
+    const unsigned ex = bits & 0x7f800000u;
+    if ((bits & 0x007fffffu) == 0u || ex < (40u << 23) || ex == 0x7f800000u) return false;
+    const double half_ulp = static_cast<double>(__uint_as_float(ex - (24u << 23)));
+    const double resid = __builtin_fabs(big - static_cast<double>(f));
+    if (!(half_ulp - resid > __builtin_fabs(big) * 0x1p-44)) return false;
+    out = f;
+    return true;
+}
 RT_DEV float julia_distance_tail_auto(float m2, float d2) {
     float r;
     if (julia_distance_tail_fast(m2, d2, r)) return r;
     return julia_distance_tail(m2, d2);
+}
+// for the march steps (escaped estimates in the vast majority)
+RT_DEV float julia_distance_tail_march(float m2, float d2) {
+    float r;
+    if (julia_distance_tail_lean(m2, d2, r)) return r;
+    return julia_distance_tail_auto(m2, d2);
 }
 
 template <bool COUNT>

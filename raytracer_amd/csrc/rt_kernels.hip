@@ -852,17 +852,21 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
 //     converged jobs are finished (6-tap normal, world-space hit) 64 at a time from the NORMAL ring.
 // One workgroup per CU; queues, contexts and results never leave LDS.
 constexpr int kPoolCtx = RT_JULIA_POOL;                       // contexts per workgroup
+constexpr int kJuliaConstTable = 16;                          // Julia sets whose constants the workgroup keeps in LDS
 constexpr int kCtxWords = 40;
 constexpr unsigned kJuliaQueueCap = 1024u;                    // a context is on at most one ring
 static_assert(kPoolCtx % 64 == 0 && kPoolCtx <= static_cast<int>(kJuliaQueueCap), "pool size");
 static_assert((kJuliaQueueCap & (kJuliaQueueCap - 1)) == 0, "ring size");
-#ifndef RT_JULIA_STEP_DIVISOR
-#define RT_JULIA_STEP_DIVISOR 2
+#ifndef RT_JULIA_NORMAL_IDLE
+#define RT_JULIA_NORMAL_IDLE 32            // a marcher wave with fewer jobs than this finishes a partial batch of converged jobs
+#endif
+#ifndef RT_JULIA_STEP_EIGHTHS
+#define RT_JULIA_STEP_EIGHTHS 5            // march steps are taken once this many eighths of a wave's jobs have one due
 #endif
 #ifndef RT_JULIA_SHADER_MIN_BATCH
 #define RT_JULIA_SHADER_MIN_BATCH 48       // a shader wave waits for this many ready contexts of one kind while the marchers have work
 #endif
-constexpr unsigned long long kStuckTicks = 400000000ull;   // 4 s of the 100 MHz clock without any progress in the workgroup
+constexpr unsigned long long kStuckTicks = 100000000ull;   // 1 s of the 100 MHz clock without any progress in the workgroup
 
 enum CtxWord : int {
     CW_QO = 0, CW_QMAX = 3, CW_QD = 4, CW_FLAGS = 7,
@@ -874,10 +878,12 @@ enum CtxFlag : unsigned { CF_KIND_MASK = 3u, CF_QACTIVE = 4u, CF_BLOCKED = 8u, C
 enum JobStatus : unsigned { JOB_PENDING = 0u, JOB_MISS = 1u, JOB_HIT = 2u };
 enum RingId : int { R_MARCH = 0, R_NORMAL = 1, R_READY_T = 2, R_READY_S = 3, R_COUNT = 4 };
 
+// Entry i of a ring lives at slot[i & (cap-1)] as ring_word(i, context id): one store publishes both.
 struct JuliaRing {
-    unsigned ids[kJuliaQueueCap];           // context id of entry i at [i & (cap-1)]
-    unsigned ready[kJuliaQueueCap];         // == i+1 once entry i has been written
+    unsigned slot[kJuliaQueueCap];
 };
+RT_DEV unsigned ring_word(unsigned i, unsigned id) { return (0x80000000u | ((i & 0x7fffu) << 16)) | id; }
+RT_DEV bool ring_word_is(unsigned v, unsigned i) { return (v >> 16) == (0x8000u | (i & 0x7fffu)); }
 struct PoolShared {
     // running counts (never wrapped) of the rings: entries head..tail-1 of ring r are reserved, ctl[2r] = head, ctl[2r+1] = tail
     __attribute__((aligned(16))) unsigned ctl[2 * R_COUNT];
@@ -885,6 +891,7 @@ struct PoolShared {
     unsigned abort;
     unsigned heartbeat;     // bumped by every wave that made progress (watchdog)
     unsigned pad;
+    __attribute__((aligned(16))) float jconst[kJuliaConstTable][8];   // c (4 floats) and the cut plane of the scene's first Julia sets
     JuliaRing ring[R_COUNT];
     __attribute__((aligned(16))) float ctx[kPoolCtx][kCtxWords];
 };
@@ -907,9 +914,8 @@ RT_DEV void ring_push(JuliaRing& q, unsigned* tail_word, bool want, unsigned id)
     base = __shfl(base, leader);
     if (want) {
         const unsigned i = base + __popcll(mask & ((1ull << lane) - 1ull));
-        lds_store(&q.ids[i & (kJuliaQueueCap - 1)], id);
         lds_release();
-        lds_store(&q.ready[i & (kJuliaQueueCap - 1)], i + 1u);
+        lds_store(&q.slot[i & (kJuliaQueueCap - 1)], ring_word(i, id));
     }
 }
 // Reserves up to `want_n` entries for this wave; returns how many and the index of the first.
@@ -935,9 +941,11 @@ RT_DEV unsigned ring_pop(unsigned* head_word, const unsigned* tail_word, unsigne
 }
 // Context id of reserved entry i (waits for the producer's write; bounded by the 100 MHz clock).
 RT_DEV unsigned ring_entry(JuliaRing& q, unsigned i, unsigned* abort_flag) {
-    if (lds_load(&q.ready[i & (kJuliaQueueCap - 1)]) != i + 1u) {
+    const unsigned* w = &q.slot[i & (kJuliaQueueCap - 1)];
+    unsigned v = lds_load(w);
+    if (!ring_word_is(v, i)) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (lds_load(&q.ready[i & (kJuliaQueueCap - 1)]) != i + 1u) {
+        while (!ring_word_is(v = lds_load(w), i)) {
             if (__builtin_amdgcn_s_memrealtime() - t0 > kStuckTicks) {
                 lds_store(abort_flag, 1u);
                 return 0u;
@@ -945,7 +953,7 @@ RT_DEV unsigned ring_entry(JuliaRing& q, unsigned i, unsigned* abort_flag) {
         }
     }
     lds_acquire();
-    return lds_load(&q.ids[i & (kJuliaQueueCap - 1)]);
+    return v & 0xffffu;
 }
 
 // A wave that has nothing to do sleeps and watches the workgroup's heartbeat: the launch is given up only when no
@@ -1090,7 +1098,7 @@ RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n) {
             if (flags.y != 0u) break;
             const unsigned n_conv = ctl.w - ctl.z, n_jobs = ctl.y - ctl.x;
             // ---- finish converged jobs: a full batch at once, a partial one when there is little else to do
-            if (n_conv >= 64u || (n_conv > 0u && n_has0 < 32 && n_jobs == 0u)) {
+            if (n_conv >= 64u || (n_conv > 0u && n_has0 < RT_JULIA_NORMAL_IDLE && n_jobs == 0u)) {
                 unsigned first = 0;
                 const unsigned got = ring_pop(&sh.ctl[2 * R_NORMAL], &sh.ctl[2 * R_NORMAL + 1], 64u, first);
                 bool to_t = false, to_s = false;
@@ -1138,10 +1146,17 @@ RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n) {
                     okind = __float_as_uint(c[CW_FLAGS]) & CF_KIND_MASK;
                     p = v3(j0.x, j0.y, j0.z);
                     d = v3(j1.x, j1.y, j1.z);
-                    const DevJulia& j = sc.julias[jidx];
-                    cp = {j.c[0], j.c[1]};
-                    cq = {j.c[2], j.c[3]};
-                    cut = j.cut_plane;
+                    if (jidx < static_cast<unsigned>(kJuliaConstTable)) {
+                        const F4 c4 = *reinterpret_cast<const F4*>(sh.jconst[jidx]);
+                        cp = {c4.x, c4.y};
+                        cq = {c4.z, c4.w};
+                        cut = sh.jconst[jidx][4];
+                    } else {
+                        const DevJulia& j = sc.julias[jidx];
+                        cp = {j.c[0], j.c[1]};
+                        cq = {j.c[2], j.c[3]};
+                        cut = j.cut_plane;
+                    }
                     jstep = 0;
                     s = julia_pk_begin({p.x, p.y, p.z, cut});
                     it = 0;
@@ -1164,17 +1179,22 @@ RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n) {
         if (STATS && has) n.v[D_MARCH_LANES]++;
         // ---- estimator iterations, four at a time, until enough lanes wait for their march step
         for (;;) {
+            if (has && busy) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (has && busy) {
+                for (int k = 0; k < 4; k++) {
                     bump<STATS>(n, C_JULIA_DE_ITERATIONS);
-                    it++;
-                    if (julia_pk_iterate(s, cp, cq) || it >= kJuliaDistanceIterations) busy = false;
+                    julia_pk_iterate_only(s, cp, cq);
+                    // (the counters build stops where the oracle's count stops: at the overflow of d2 itself)
+                    if (s.m2 > 1e10f || (STATS && s.d2 == __builtin_inff())) break;
                 }
+                it++;   // blocks of four
+                // exact early-out once d2 has overflowed, looked at once per block: further iterations
+                // cannot change the value the march uses
+                if (s.m2 > 1e10f || s.d2 == __builtin_inff() || it >= kJuliaDistanceIterations / 4) busy = false;
             }
             if (STATS && lane == 0) n.v[D_DE_WAVE_ITERS] += 256ull;
             const int n_busy = __popcll(__ballot(has && busy));
-            if (n_busy == 0 || (n_has - n_busy) * RT_JULIA_STEP_DIVISOR >= n_has) break;
+            if (n_busy == 0 || (n_has - n_busy) * 8 >= n_has * RT_JULIA_STEP_EIGHTHS) break;
         }
         charge(D_MARCH_CYCLES);
         if (STATS && lane == 0) n.v[D_M_TAIL_BLOCKS]++;
@@ -1183,7 +1203,7 @@ RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n) {
         bool converged = false, miss_t = false, miss_s = false;
         if (has && !busy) {
             bump<STATS>(n, C_JULIA_STEPS);
-            const int r = julia_advance(julia_distance_tail_auto(s.m2, s.d2), p, d, jstep);
+            const int r = julia_advance(julia_distance_tail_march(s.m2, s.d2), p, d, jstep);
             if (r == 0) {
                 s = julia_pk_begin({p.x, p.y, p.z, cut});
                 it = 0;
@@ -1351,12 +1371,15 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
     __shared__ PoolShared sh;
     const DevScene& sc = sc_global;
     for (unsigned i = threadIdx.x; i < kJuliaQueueCap; i += blockDim.x) {
-        for (int r = 0; r < R_COUNT; r++) sh.ring[r].ready[i] = 0u;
+        for (int r = 0; r < R_COUNT; r++) sh.ring[r].slot[i] = 0u;
         // every context starts on READY_T, asking for its first sample
         if (i < static_cast<unsigned>(kPoolCtx)) {
-            sh.ring[R_READY_T].ids[i] = i;
-            sh.ring[R_READY_T].ready[i] = i + 1u;
+            sh.ring[R_READY_T].slot[i] = ring_word(i, i);
             sh.ctx[i][CW_FLAGS] = __uint_as_float(CF_FRESH);
+        }
+        if (i < static_cast<unsigned>(kJuliaConstTable) && i < sc.n_julias) {
+            for (int k = 0; k < 4; k++) sh.jconst[i][k] = sc.julias[i].c[k];
+            sh.jconst[i][4] = sc.julias[i].cut_plane;
         }
     }
     if (threadIdx.x == 0) {

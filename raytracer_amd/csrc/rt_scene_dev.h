@@ -204,10 +204,10 @@ constexpr uint32_t kDepositLongRun = 32;    // deposits into one texel from whic
 #define RT_JULIA_WAVES 12
 #endif
 #ifndef RT_JULIA_MARCHERS
-#define RT_JULIA_MARCHERS 8
+#define RT_JULIA_MARCHERS 9
 #endif
 #ifndef RT_JULIA_POOL
-#define RT_JULIA_POOL 768
+#define RT_JULIA_POOL 896
 #endif
 constexpr int kJuliaWaves = RT_JULIA_WAVES;              // per workgroup, a multiple of 4 (waves per SIMD = kJuliaWaves / 4)
 constexpr int kJuliaMarcherWaves = RT_JULIA_MARCHERS;    // the rest are shader waves

@@ -20,3 +20,9 @@ def test_fast_tail_model_agrees_with_the_reference_expression(tmp_path):
     # arbitrary operands, including infinities, zeros and denormals: wrong answers are never allowed
     out = subprocess.run([str(exe), "3000000"], capture_output=True, text=True, check=True).stdout
     assert "bad=0" in out, out
+    # the march's lean tail (julia_distance_tail_lean, falling back to the fast one): same bars
+    out = subprocess.run([str(exe), "3000000", "march", "lean"], capture_output=True, text=True, check=True).stdout
+    assert "bad=0" in out, out
+    assert float(out.split("(")[-1].split(")")[0]) < 1e-4, out
+    out = subprocess.run([str(exe), "3000000", "any", "lean"], capture_output=True, text=True, check=True).stdout
+    assert "bad=0" in out, out
