@@ -858,10 +858,13 @@ constexpr unsigned kJuliaQueueCap = 1024u;                    // a context is on
 static_assert(kPoolCtx % 64 == 0 && kPoolCtx <= static_cast<int>(kJuliaQueueCap), "pool size");
 static_assert((kJuliaQueueCap & (kJuliaQueueCap - 1)) == 0, "ring size");
 #ifndef RT_JULIA_NORMAL_IDLE
-#define RT_JULIA_NORMAL_IDLE 32            // a marcher wave with fewer jobs than this finishes a partial batch of converged jobs
+#define RT_JULIA_NORMAL_IDLE 8             // a marcher wave with fewer jobs than this finishes a partial batch of converged jobs
 #endif
 #ifndef RT_JULIA_STEP_EIGHTHS
 #define RT_JULIA_STEP_EIGHTHS 5            // march steps are taken once this many eighths of a wave's jobs have one due
+#endif
+#ifndef RT_JULIA_JOBS_AHEAD
+#define RT_JULIA_JOBS_AHEAD 64u            // queued Julia jobs above which a shader wave may wait for a fuller batch
 #endif
 #ifndef RT_JULIA_SHADER_MIN_BATCH
 #define RT_JULIA_SHADER_MIN_BATCH 48       // a shader wave waits for this many ready contexts of one kind while the marchers have work
@@ -1256,7 +1259,7 @@ RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob&
         const int r = n_t >= n_s ? R_READY_T : R_READY_S;
         const unsigned n_ready = n_t >= n_s ? n_t : n_s;
         // a full batch at once; a partial one when the marchers are about to run out of jobs, or after a while
-        if (n_ready == 0u || (n_ready < static_cast<unsigned>(RT_JULIA_SHADER_MIN_BATCH) && n_jobs >= 64u && patience < 16u)) {
+        if (n_ready == 0u || (n_ready < static_cast<unsigned>(RT_JULIA_SHADER_MIN_BATCH) && n_jobs >= RT_JULIA_JOBS_AHEAD && patience < 16u)) {
             if (n_ready == 0u) idle_wait(sh, watch); else __builtin_amdgcn_s_sleep(4);
             patience++;
             charge(D_T_WAIT_CYCLES);

@@ -204,7 +204,7 @@ constexpr uint32_t kDepositLongRun = 32;    // deposits into one texel from whic
 #define RT_JULIA_WAVES 12
 #endif
 #ifndef RT_JULIA_MARCHERS
-#define RT_JULIA_MARCHERS 9
+#define RT_JULIA_MARCHERS 10
 #endif
 #ifndef RT_JULIA_POOL
 #define RT_JULIA_POOL 896
