@@ -688,15 +688,17 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
         o.pad = 0.0f;
     }
     std::vector<DevTexture> texs(d->n_textures);
-    std::vector<float4> texels;
+    std::vector<uint32_t> texels;     // RGBA8 as given; the kernels form u8 / 255.0f themselves (rt_intersect.h: unorm8)
     for (uint32_t i = 0; i < d->n_textures; i++) {
         const rt_texture& t = d->textures[i];
         texs[i] = {t.width, t.height, static_cast<uint32_t>(texels.size()), 0u};
         const uint8_t* src = d->texels + t.offset;
         const size_t n = static_cast<size_t>(t.width) * t.height;
+        const size_t at = texels.size();
+        texels.resize(at + n);
         for (size_t k = 0; k < n; k++) {
-            // Color(UColor): u8 / 255.0f per channel (src/types.h:272)
-            texels.push_back(make_float4(src[k * 4 + 0] / 255.0f, src[k * 4 + 1] / 255.0f, src[k * 4 + 2] / 255.0f, src[k * 4 + 3] / 255.0f));
+            texels[at + k] = static_cast<uint32_t>(src[k * 4 + 0]) | (static_cast<uint32_t>(src[k * 4 + 1]) << 8) |
+                             (static_cast<uint32_t>(src[k * 4 + 2]) << 16) | (static_cast<uint32_t>(src[k * 4 + 3]) << 24);
         }
     }
     if (texels.size() > 0xffffffffull) return fail(ctx, RT_ERR_LIMIT, "texture pool too large");

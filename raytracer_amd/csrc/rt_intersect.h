@@ -482,7 +482,19 @@ RT_DEV bool julia_intersect_inline(const DevJulia& j, V3 o_w, V3 d_w, float maxd
 }
 
 // ---- texture (src/raytracer.cpp:166-199) -------------------------------------------------------
-RT_DEV Col texture_bilinear(const DevTexture& tex, const float4* __restrict__ texels, V2 uv) {
+// Color(UColor) = u8 / 255.0f per channel (src/types.h:272), formed on the fly from the RGBA8 texel: q = x*r with
+// r = fl(1/255) corrected by one residual step equals the correctly rounded quotient for every x in 0..255
+// (checked exhaustively: tests/test_unorm8.py; x*r alone is wrong for 126
+// of them).  Textures stay 4 bytes per texel in HBM/L2 instead of 16.
+RT_DEV float unorm8(unsigned x) {
+    const float xf = static_cast<float>(x);
+    const float r = 1.0f / 255.0f;
+    const float a = xf * r;
+    const float e = __builtin_fmaf(-a, 255.0f, xf);
+    return __builtin_fmaf(e, r, a);
+}
+RT_DEV Col texel_color(unsigned t) { return {unorm8(t & 255u), unorm8((t >> 8) & 255u), unorm8((t >> 16) & 255u), unorm8(t >> 24)}; }
+RT_DEV Col texture_bilinear(const DevTexture& tex, const uint32_t* __restrict__ texels, V2 uv) {
     const unsigned w = tex.width, hgt = tex.height;
     uv.x = frac_part(uv.x);
     uv.y = frac_part(uv.y);
@@ -491,11 +503,10 @@ RT_DEV Col texture_bilinear(const DevTexture& tex, const float4* __restrict__ te
     const unsigned x1 = clamp_u32(cast_u32(ceilf(px)), 0u, w - 1), y1 = clamp_u32(cast_u32(ceilf(py)), 0u, hgt - 1);
     const float fx = frac_part(px), fy = frac_part(py);
     const float f1 = (1 - fx) * (1 - fy), f2 = fx * (1 - fy), f3 = (1 - fx) * fy, f4 = fx * fy;
-    const float4* base = texels + tex.first_texel;
-    const float4 t1 = base[static_cast<size_t>(y0) * w + x0], t2 = base[static_cast<size_t>(y0) * w + x1];
-    const float4 t3 = base[static_cast<size_t>(y1) * w + x0], t4 = base[static_cast<size_t>(y1) * w + x1];
-    const Col c1 = {t1.x, t1.y, t1.z, t1.w}, c2 = {t2.x, t2.y, t2.z, t2.w}, c3 = {t3.x, t3.y, t3.z, t3.w}, c4 = {t4.x, t4.y, t4.z, t4.w};
-    return c1 * f1 + c2 * f2 + c3 * f3 + c4 * f4;
+    const uint32_t* base = texels + tex.first_texel;
+    const uint32_t t1 = base[static_cast<size_t>(y0) * w + x0], t2 = base[static_cast<size_t>(y0) * w + x1];
+    const uint32_t t3 = base[static_cast<size_t>(y1) * w + x0], t4 = base[static_cast<size_t>(y1) * w + x1];
+    return texel_color(t1) * f1 + texel_color(t2) * f2 + texel_color(t3) * f3 + texel_color(t4) * f4;
 }
 
 // ---- Fresnel (src/raytracer.cpp:243-268, again at src/photonmap.cpp:92-116) ---------------------

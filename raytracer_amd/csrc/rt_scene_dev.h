@@ -74,7 +74,7 @@ struct DevMaterial {
 };
 struct DevTexture {
     uint32_t width, height;
-    uint32_t first_texel;    // into the float4 texel pool
+    uint32_t first_texel;    // into the RGBA8 texel pool
     uint32_t pad;
 };
 struct DevLight {
@@ -127,7 +127,7 @@ struct DevScene {
     const int32_t* object_photon_slot; // [n_objects] slot in the photon atlas or -1
     const DevMaterial* materials;
     const DevTexture* textures;
-    const float4* texels;
+    const uint32_t* texels;            // RGBA8 as in rt_scene_desc (R in the low byte)
     const DevBvhNode* bvh_nodes;
     const uint32_t* bvh_prims;         // triangle indices (into tri_test) in leaf order
 
