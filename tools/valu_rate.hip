@@ -62,6 +62,16 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, float seed) {
             if (KIND == 21) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
             if (KIND == 22) asm volatile("v_rsq_f64 %0, %0" : "+v"(d[i]));
             if (KIND == 23) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[i]) : "v"(a[i]));
+            if (KIND == 24) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i]) : "s"(seed));             // SGPR operand, no clobber
+            if (KIND == 25) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(a[i]));                           // inline constant
+            if (KIND == 26) asm volatile("v_mul_f32 %0, 0x3f800001, %0" : "+v"(a[i]));                    // 32-bit literal
+            if (KIND == 27) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(a[i]) : "s"(seed));
+            if (KIND == 28) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(seed), "v"(c));
+            if (KIND == 29) asm volatile("v_max_f32 %0, %0, %1\n\tv_min_f32 %0, %0, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+            if (KIND == 30) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "s"(seed));
+            if (KIND == 31) asm volatile("v_cmp_gt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m) : "vcc");
+            if (KIND == 32) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            if (KIND == 33) asm volatile("v_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %2, %0" : "+v"(a[i]) : "v"(m), "s"(seed));   // alternating VGPR / SGPR
         }
     }
     float s = 0.0f;
@@ -86,7 +96,7 @@ void run(const char* name, float* d_out, int n_cus, double ops_per_instr) {
         float ms = 0;
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         ms /= 3;
-        const double instr_per_simd = static_cast<double>(kIters) * kUnroll * (KIND == 15 ? 2 : 1) * wps;
+        const double instr_per_simd = static_cast<double>(kIters) * kUnroll * ((KIND == 15 || KIND == 29 || KIND == 31 || KIND == 33) ? 2 : 1) * wps;
         const double cyc = ms * 1e-3 * 2.4e9 / instr_per_simd;   // cycles at 2.4 GHz per wave-instruction per SIMD
         printf("  w/simd=%d: %6.2f cyc/instr", wps, cyc);
         (void)ops_per_instr;
@@ -125,5 +135,15 @@ int main() {
     run<21>("v_exp_f32", d_out, n_cus, 1);
     run<22>("v_rsq_f64", d_out, n_cus, 1);
     run<23>("v_cvt_f64_f32", d_out, n_cus, 1);
+    run<24>("v_mul_f32 sgpr (arg)", d_out, n_cus, 1);
+    run<25>("v_add_f32 inline const", d_out, n_cus, 1);
+    run<26>("v_mul_f32 literal", d_out, n_cus, 1);
+    run<27>("v_sub_f32 sgpr", d_out, n_cus, 1);
+    run<28>("v_fma_f32 sgpr", d_out, n_cus, 1);
+    run<29>("v_max,v_min pair", d_out, n_cus, 1);
+    run<30>("v_mov_b32 from sgpr", d_out, n_cus, 1);
+    run<31>("v_cmp + v_cndmask", d_out, n_cus, 1);
+    run<32>("v_xor_b32", d_out, n_cus, 1);
+    run<33>("v_mul vgpr, v_mul sgpr", d_out, n_cus, 1);
     return 0;
 }
