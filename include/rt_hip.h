@@ -212,6 +212,20 @@ int rt_photon_generate(rt_ctx* ctx, rt_stats* stats_or_null);
  * layout of Picture (reference src/types.h:385). */
 int rt_render(rt_ctx* ctx, const rt_bands* bands_or_null, float* rgba_out, rt_stats* stats_or_null);
 
+/* raytrace + Color::scaleOut for the writers: what the reference's four loops do with the Picture they get back is
+ * quantise it (writePNG / writeAPNGFrame -> Color::scaleOut, reference src/pngwriter.cpp:205-216, src/types.h:274-282),
+ * after accumulating sub-frames for motion blur (Picture::mulAdd, reference src/main.cpp:64,147).  These three do
+ * that on the device, so that 4 bytes per pixel cross the host link instead of 16 (the float frame's copy
+ * takes longer than the render):
+ *   rt_render_rgba8          picture -> RGBA8 (u8(clamp(v*gain,0,1)*255.0f), truncating) into caller-owned host memory
+ *   rt_render_accumulate     acc = (first ? 0 : acc) + picture * weight, element by element in the rounding order of
+ *                            Picture::mulAdd; the accumulated picture stays on the device, inside the context
+ *   rt_accumulated_rgba8     the accumulated picture -> RGBA8 into caller-owned host memory
+ * Synchronous, default stream; `rgba8_out` holds rt_bands_pixel_count()*4 bytes. */
+int rt_render_rgba8(rt_ctx* ctx, const rt_bands* bands_or_null, uint8_t* rgba8_out, float gain, rt_stats* stats_or_null);
+int rt_render_accumulate(rt_ctx* ctx, const rt_bands* bands_or_null, float weight, int first);
+int rt_accumulated_rgba8(rt_ctx* ctx, const rt_bands* bands_or_null, uint8_t* rgba8_out, float gain);
+
 /* Same, but `d_rgba_out` is DEVICE memory on the context's GPU and the kernels are enqueued on
  * `hip_stream` (a hipStream_t passed as void*, NULL = the default stream) without synchronising.
  * This is the entry point the multi-GPU driver uses so that frames stay in HBM for the RCCL gather.

@@ -78,7 +78,17 @@ struct rt_ctx {
     std::string error;
     bool has_scene = false;
     DevScene dev{};
-    std::vector<void*> scene_allocs;
+    // the uploaded scene's tables live in ONE device allocation that is kept and reused from upload to upload (a
+    // frame of an animation re-uploads a scene of the same size 20 x K times): tables are packed into a pinned host
+    // block and go over with a single asynchronous copy; nothing is freed or allocated unless the scene outgrows it
+    Buffer scene_arena, bvh_nodes, atlas;
+    unsigned char* h_arena = nullptr;      // pinned staging
+    size_t h_arena_bytes = 0;
+    std::vector<unsigned char> stage;      // tables of the upload in progress
+    struct PendingPtr { size_t offset; const void** slot; };
+    std::vector<PendingPtr> pending;
+    hipEvent_t ev_upload = nullptr;        // the last upload's copy has left the pinned block
+    bool upload_in_flight = false;
     // host-side facts about the uploaded scene
     uint32_t n_objects = 0, n_slots = 0;
     std::vector<int32_t> photon_slot;
@@ -87,9 +97,9 @@ struct rt_ctx {
     float photon_steps = 0.0f;
     uint32_t hues = 1;
     // photon tables
-    Buffer photon_tables;
+    const float* d_photon_tables = nullptr;   // sin/cos of phi, sin/cos of theta (in the scene arena)
     uint32_t n_phi = 0, n_theta = 0;
-    uint32_t* d_point_lights = nullptr;
+    const uint32_t* d_point_lights = nullptr;
     // options
     bool collect_stats = false;
     int64_t bvh_min_triangles = 256;  // below this the chunk-culled scan wins (C2, 64 triangles: 2.9 ms against 3.9 ms with the BVH)
@@ -107,7 +117,9 @@ struct rt_ctx {
     bool dep_last_pass_overflowed = false;   // sticky until the next pass is enqueued
     bool dep_key_too_narrow = false;         // a root made more deposits than the order key has bits for
     // per-call scratch, grown on demand and kept
-    Buffer samples, stack, out_staging, kat_a, kat_b, kat_c, kat_d;
+    Buffer samples, stack, out_staging, out8, acc, kat_a, kat_b, kat_c, kat_d;
+    unsigned char* h_out = nullptr;        // pinned block the synchronous entry points copy their pictures through
+    size_t h_out_bytes = 0;
     unsigned long long* d_queue = nullptr;      // [0] = queue head, [1] = watchdog flag of trace_julia_kernel (sticky until read)
     unsigned long long* h_status = nullptr;     // pinned copy of d_queue[1], written by the stream after every render launch
     bool status_pending = false;                // a render launch whose watchdog word has not been looked at yet
@@ -150,21 +162,52 @@ int grow(rt_ctx* ctx, Buffer& b, size_t bytes) {
     return RT_OK;
 }
 
+// Places a table in the upload's staging block; *out receives its device address in flush_uploads.
 template <typename T>
 int upload(rt_ctx* ctx, const std::vector<T>& host, const T** out) {
     *out = nullptr;
     const size_t bytes = (host.empty() ? 1 : host.size()) * sizeof(T);
-    void* d = nullptr;
-    RT_HIP_TRY(ctx, hipMalloc(&d, bytes));
-    ctx->scene_allocs.push_back(d);
-    if (!host.empty()) RT_HIP_TRY(ctx, hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
-    *out = static_cast<const T*>(d);
+    const size_t offset = (ctx->stage.size() + 255) & ~size_t(255);
+    ctx->stage.resize(offset + bytes, 0);
+    if (!host.empty()) std::memcpy(ctx->stage.data() + offset, host.data(), host.size() * sizeof(T));
+    ctx->pending.push_back({offset, reinterpret_cast<const void**>(out)});
+    return RT_OK;
+}
+
+// Sends the staged tables with one copy on the default stream and resolves the pending pointers.
+int flush_uploads(rt_ctx* ctx) {
+    const size_t bytes = ctx->stage.size();
+    if (bytes == 0) return RT_OK;
+    if (ctx->scene_arena.bytes < bytes) {
+        // the scene outgrew the arena: only now is anything freed, so only now must the device be idle
+        RT_HIP_TRY(ctx, hipDeviceSynchronize());
+        const int rc = grow(ctx, ctx->scene_arena, bytes + bytes / 4);
+        if (rc != RT_OK) return rc;
+    }
+    if (ctx->upload_in_flight) {
+        RT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_upload));   // the pinned block is free again
+        ctx->upload_in_flight = false;
+    }
+    if (ctx->h_arena_bytes < bytes) {
+        if (ctx->h_arena) RT_HIP_TRY(ctx, hipHostFree(ctx->h_arena));
+        ctx->h_arena = nullptr;
+        ctx->h_arena_bytes = 0;
+        RT_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_arena), bytes + bytes / 4));
+        ctx->h_arena_bytes = bytes + bytes / 4;
+    }
+    std::memcpy(ctx->h_arena, ctx->stage.data(), bytes);
+    RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->scene_arena.ptr, ctx->h_arena, bytes, hipMemcpyHostToDevice, nullptr));
+    RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_upload, nullptr));
+    ctx->upload_in_flight = true;
+    for (const rt_ctx::PendingPtr& p : ctx->pending) *p.slot = static_cast<const unsigned char*>(ctx->scene_arena.ptr) + p.offset;
+    ctx->pending.clear();
+    ctx->stage.clear();
     return RT_OK;
 }
 
 void free_scene(rt_ctx* ctx) {
-    for (void* p : ctx->scene_allocs) (void)hipFree(p);
-    ctx->scene_allocs.clear();
+    ctx->pending.clear();
+    ctx->stage.clear();
     ctx->has_scene = false;
 }
 
@@ -287,6 +330,7 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     job.queue_head = ws.queue;
     job.counters = ws.counters;
     job.debug_abort = ctx->debug_force_abort ? 1u : 0u;
+    if (ctx->upload_in_flight && stream != nullptr) RT_HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ev_upload, 0));   // the scene's copy ran on the default stream
     if (fixed != nullptr) {
         // the fixed workspace is shared by every call on this GPU and keeps the last call's contents: both queue
         // words and the counters start at zero (the frame stacks and the sample buffer are written before they are read)
@@ -375,13 +419,14 @@ int deposit_buffers(rt_ctx* ctx, unsigned long long all_roots, unsigned key_bits
 
 int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t n_parts = 1) {
     if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_photon_generate before rt_scene_upload");
+    if (ctx->upload_in_flight && stream != nullptr) RT_HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ev_upload, 0));
     RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long), stream));
     RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
     if (ctx->photon_steps > 0.0f && ctx->n_slots > 0 && !ctx->point_lights.empty() && ctx->n_phi > 0 && ctx->n_theta > 0) {
         const size_t atlas_bytes = static_cast<size_t>(ctx->n_slots) * ctx->dev.photon_size * ctx->dev.photon_size * sizeof(float4);
         RT_HIP_TRY(ctx, hipMemsetAsync(ctx->dev.photon_atlas, 0, atlas_bytes, stream));
         DevPhotonJob job{};
-        const float* t = static_cast<const float*>(ctx->photon_tables.ptr);
+        const float* t = ctx->d_photon_tables;
         job.sin_phi = t;
         job.cos_phi = t + ctx->n_phi;
         job.sin_theta = t + 2 * ctx->n_phi;
@@ -492,6 +537,70 @@ int read_stats(rt_ctx* ctx, rt_stats* out) {
     return RT_OK;
 }
 
+// Device -> caller's host memory through the context's pinned block (a pageable hipMemcpy stages through the
+// runtime's own small bounce buffers at a fraction of the link rate); very large pictures go directly.
+int download(rt_ctx* ctx, void* host_out, const void* d_src, size_t bytes) {
+    constexpr size_t kPinnedCap = size_t(1) << 30;
+    if (bytes > kPinnedCap) {
+        RT_HIP_TRY(ctx, hipMemcpy(host_out, d_src, bytes, hipMemcpyDeviceToHost));
+        return RT_OK;
+    }
+    if (ctx->h_out_bytes < bytes) {
+        if (ctx->h_out) RT_HIP_TRY(ctx, hipHostFree(ctx->h_out));
+        ctx->h_out = nullptr;
+        ctx->h_out_bytes = 0;
+        RT_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_out), bytes));
+        ctx->h_out_bytes = bytes;
+    }
+    RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, d_src, bytes, hipMemcpyDeviceToHost, nullptr));
+    RT_HIP_TRY(ctx, hipStreamSynchronize(nullptr));
+    std::memcpy(host_out, ctx->h_out, bytes);
+    return RT_OK;
+}
+
+// Color::scaleOut on the device, then 4 bytes per pixel over the link instead of 16.
+int download_rgba8(rt_ctx* ctx, const float4* d_rgba, uint64_t n_pixels, float gain, uint8_t* out) {
+    int rc = grow(ctx, ctx->out8, n_pixels * 4);
+    if (rc != RT_OK) return rc;
+    const unsigned g = static_cast<unsigned>((n_pixels + 255) / 256);
+    hipLaunchKernelGGL(quantize_kernel, dim3(g), dim3(256), 0, nullptr, d_rgba, static_cast<uchar4*>(ctx->out8.ptr), gain, n_pixels);
+    RT_HIP_TRY(ctx, hipGetLastError());
+    return download(ctx, out, ctx->out8.ptr, n_pixels * 4);
+}
+
+// The photon scan angles (src/photonmap.cpp:38-45) are accumulated in float by the reference's loops; the same loops
+// produce them here, and the tables ride in the upload's staging block together with the point-light list.
+int stage_photon_tables(rt_ctx* ctx, const rt_scene_desc* d, bool dispersion) {
+    ctx->photon_steps = d->photon_steps;
+    ctx->hues = dispersion ? 8u : 1u;
+    ctx->n_phi = ctx->n_theta = 0;
+    ctx->d_photon_tables = nullptr;
+    ctx->d_point_lights = nullptr;
+    if (!(d->photon_steps > 0.0f)) return RT_OK;
+    const float step = 2 * 3.14159265358979323846f / d->photon_steps;
+    std::vector<float> sp, cp, st, ct;
+    if (!(step > 0.0f)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "photon_steps gives a non-positive scan step");
+    for (float phi = 0.0f; phi < 2 * 3.14159265358979323846f; phi += step) {
+        sp.push_back(sinf(phi));
+        cp.push_back(cosf(phi));
+        if (sp.size() > (1u << 24)) return fail(ctx, RT_ERR_LIMIT, "photon_steps too large");
+    }
+    for (float theta = 0.0f; theta < 3.14159265358979323846f; theta += step) {
+        st.push_back(sinf(theta));
+        ct.push_back(cosf(theta));
+    }
+    ctx->n_phi = static_cast<uint32_t>(sp.size());
+    ctx->n_theta = static_cast<uint32_t>(st.size());
+    std::vector<float> all;
+    all.insert(all.end(), sp.begin(), sp.end());
+    all.insert(all.end(), cp.begin(), cp.end());
+    all.insert(all.end(), st.begin(), st.end());
+    all.insert(all.end(), ct.begin(), ct.end());
+    int rc;
+    if ((rc = upload(ctx, all, &ctx->d_photon_tables)) != RT_OK) return rc;
+    return upload(ctx, ctx->point_lights, &ctx->d_point_lights);
+}
+
 }  // namespace
 
 extern "C" {
@@ -538,7 +647,7 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
         hipMalloc(reinterpret_cast<void**>(&ctx->d_dep_words), 4 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->h_dep_words), 4 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), sizeof(unsigned long long)) != hipSuccess ||
-        hipEventCreate(&ctx->ev_dep) != hipSuccess ||
+        hipEventCreate(&ctx->ev_dep) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) {
         delete ctx;
         return fail(nullptr, RT_ERR_HIP, "cannot allocate context resources on device %d", device_id);
@@ -566,7 +675,10 @@ void rt_destroy(rt_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     free_scene(ctx);
-    for (Buffer* b : {&ctx->samples, &ctx->stack, &ctx->out_staging, &ctx->photon_tables, &ctx->kat_a, &ctx->kat_b, &ctx->kat_c, &ctx->kat_d,
+    if (ctx->h_arena) (void)hipHostFree(ctx->h_arena);
+    if (ctx->h_out) (void)hipHostFree(ctx->h_out);
+    if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
+    for (Buffer* b : {&ctx->scene_arena, &ctx->bvh_nodes, &ctx->atlas, &ctx->out8, &ctx->acc, &ctx->samples, &ctx->stack, &ctx->out_staging, &ctx->kat_a, &ctx->kat_b, &ctx->kat_c, &ctx->kat_d,
                       &ctx->dep_keys, &ctx->dep_vals, &ctx->dep_sorted_keys, &ctx->dep_sorted_index, &ctx->dep_long_runs, &ctx->dep_temp}) {
         if (b->ptr) (void)hipFree(b->ptr);
     }
@@ -574,7 +686,6 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->h_dep_words) (void)hipHostFree(ctx->h_dep_words);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->ev_dep) (void)hipEventDestroy(ctx->ev_dep);
-    if (ctx->d_point_lights) (void)hipFree(ctx->d_point_lights);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -623,7 +734,9 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
     if (d->photon_steps > 0.0f && d->photon_texture_size == 0) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "photon_texture_size must be > 0 when photon_steps > 0");
 
     RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    RT_HIP_TRY(ctx, hipDeviceSynchronize());
+    // the tables are overwritten in place by a copy on the default stream: it must run after the work enqueued on
+    // this context so far (an event wait on the device; the host does not block)
+    if (ctx->events_pending) RT_HIP_TRY(ctx, hipStreamWaitEvent(nullptr, ctx->ev_end, 0));
     free_scene(ctx);
     DevScene& sc = ctx->dev;
     std::memset(&sc, 0, sizeof sc);
@@ -906,6 +1019,9 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
         blob.resize((blob.size() + 15) & ~size_t(15), 0);
         const unsigned char* d_blob = nullptr;
         if ((rc = upload(ctx, blob, &d_blob)) != RT_OK) return rc;
+        // photon scan tables and the point-light list ride in the same block
+        if ((rc = stage_photon_tables(ctx, d, sc.dispersion != 0)) != RT_OK) return rc;
+        if ((rc = flush_uploads(ctx)) != RT_OK) return rc;     // every pointer staged so far is valid from here on
         sc.shade_blob = d_blob;
         sc.shade_blob_bytes = static_cast<uint32_t>(blob.size());
         sc.shade_blob_in_lds = blob.size() <= kMaxLdsBlobBytes ? 1u : 0u;
@@ -941,9 +1057,9 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
             if (qualifies(r)) total_nodes += 2 * size_t(r.count) - 1;
         }
         if (total_nodes > 0) {
-            void* d_nodes = nullptr;
-            RT_HIP_TRY(ctx, hipMalloc(&d_nodes, total_nodes * sizeof(DevBvhNode)));
-            ctx->scene_allocs.push_back(d_nodes);
+            if (ctx->bvh_nodes.bytes < total_nodes * sizeof(DevBvhNode)) RT_HIP_TRY(ctx, hipDeviceSynchronize());
+            if ((rc = grow(ctx, ctx->bvh_nodes, total_nodes * sizeof(DevBvhNode))) != RT_OK) return rc;
+            void* d_nodes = ctx->bvh_nodes.ptr;
             size_t at = 0;
             for (DevRun& r : runs) {
                 if (qualifies(r)) {
@@ -959,48 +1075,16 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
         }
     }
 
-    // ---- photon atlas and scan tables (src/photonmap.cpp:38-45) ----------------------------------------
-    ctx->photon_steps = d->photon_steps;
-    ctx->hues = sc.dispersion ? 8u : 1u;
+    // ---- photon atlas (the scan tables were staged with the scene tables: stage_photon_tables) -------------------
     sc.photon_size = d->photon_texture_size;
     sc.photon_factor = d->photon_factor;
     sc.photon_atlas = nullptr;
-    ctx->n_phi = ctx->n_theta = 0;
     if (d->photon_steps > 0.0f && ctx->n_slots > 0) {
         const size_t atlas_bytes = static_cast<size_t>(ctx->n_slots) * sc.photon_size * sc.photon_size * sizeof(float4);
-        void* atlas = nullptr;
-        RT_HIP_TRY(ctx, hipMalloc(&atlas, atlas_bytes));
-        ctx->scene_allocs.push_back(atlas);
-        RT_HIP_TRY(ctx, hipMemset(atlas, 0, atlas_bytes));
-        sc.photon_atlas = static_cast<float4*>(atlas);
-    }
-    if (d->photon_steps > 0.0f) {
-        // the scan angles are accumulated in float by the reference's loops; reproduce them exactly
-        const float step = 2 * 3.14159265358979323846f / d->photon_steps;
-        std::vector<float> sp, cp, st, ct;
-        if (!(step > 0.0f)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "photon_steps gives a non-positive scan step");
-        for (float phi = 0.0f; phi < 2 * 3.14159265358979323846f; phi += step) {
-            sp.push_back(sinf(phi));
-            cp.push_back(cosf(phi));
-            if (sp.size() > (1u << 24)) return fail(ctx, RT_ERR_LIMIT, "photon_steps too large");
-        }
-        for (float theta = 0.0f; theta < 3.14159265358979323846f; theta += step) {
-            st.push_back(sinf(theta));
-            ct.push_back(cosf(theta));
-        }
-        ctx->n_phi = static_cast<uint32_t>(sp.size());
-        ctx->n_theta = static_cast<uint32_t>(st.size());
-        std::vector<float> all;
-        all.insert(all.end(), sp.begin(), sp.end());
-        all.insert(all.end(), cp.begin(), cp.end());
-        all.insert(all.end(), st.begin(), st.end());
-        all.insert(all.end(), ct.begin(), ct.end());
-        if ((rc = grow(ctx, ctx->photon_tables, all.size() * sizeof(float))) != RT_OK) return rc;
-        RT_HIP_TRY(ctx, hipMemcpy(ctx->photon_tables.ptr, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice));
-        if (ctx->d_point_lights) (void)hipFree(ctx->d_point_lights);
-        ctx->d_point_lights = nullptr;
-        RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_point_lights), (ctx->point_lights.size() + 1) * sizeof(uint32_t)));
-        if (!ctx->point_lights.empty()) RT_HIP_TRY(ctx, hipMemcpy(ctx->d_point_lights, ctx->point_lights.data(), ctx->point_lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (ctx->atlas.bytes < atlas_bytes) RT_HIP_TRY(ctx, hipDeviceSynchronize());
+        if ((rc = grow(ctx, ctx->atlas, atlas_bytes)) != RT_OK) return rc;
+        RT_HIP_TRY(ctx, hipMemsetAsync(ctx->atlas.ptr, 0, atlas_bytes, nullptr));
+        sc.photon_atlas = static_cast<float4*>(ctx->atlas.ptr);
     }
     {
         // persistent-grid sizes of the render kernels for this scene (the LDS copy of the shade blob decides), asked
@@ -1106,8 +1190,51 @@ int rt_render(rt_ctx* ctx, const rt_bands* bands, float* rgba_out, rt_stats* sta
     if (rc != RT_OK) return rc;
     rc = render_enqueue(ctx, bands, static_cast<float4*>(ctx->out_staging.ptr), nullptr);
     if (rc != RT_OK) return rc;
-    RT_HIP_TRY(ctx, hipMemcpy(rgba_out, ctx->out_staging.ptr, n_pixels * sizeof(float4), hipMemcpyDeviceToHost));
+    if ((rc = download(ctx, rgba_out, ctx->out_staging.ptr, n_pixels * sizeof(float4))) != RT_OK) return rc;
     return read_stats(ctx, stats);
+}
+
+int rt_render_rgba8(rt_ctx* ctx, const rt_bands* bands, uint8_t* rgba8_out, float gain, rt_stats* stats) {
+    if (ctx == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    if (rgba8_out == nullptr) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render_rgba8: output pointer is NULL");
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_render_rgba8 before rt_scene_upload");
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_pixels = rt_bands_pixel_count(ctx->dev.width, ctx->dev.height, bands);
+    if (n_pixels == 0) return read_stats(ctx, stats);
+    int rc = grow(ctx, ctx->out_staging, n_pixels * sizeof(float4));
+    if (rc != RT_OK) return rc;
+    if ((rc = render_enqueue(ctx, bands, static_cast<float4*>(ctx->out_staging.ptr), nullptr)) != RT_OK) return rc;
+    if ((rc = download_rgba8(ctx, static_cast<const float4*>(ctx->out_staging.ptr), n_pixels, gain, rgba8_out)) != RT_OK) return rc;
+    return read_stats(ctx, stats);
+}
+
+int rt_render_accumulate(rt_ctx* ctx, const rt_bands* bands, float weight, int first) {
+    if (ctx == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_render_accumulate before rt_scene_upload");
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_pixels = rt_bands_pixel_count(ctx->dev.width, ctx->dev.height, bands);
+    if (n_pixels == 0) return RT_OK;
+    int rc = grow(ctx, ctx->out_staging, n_pixels * sizeof(float4));
+    if (rc != RT_OK) return rc;
+    if (ctx->acc.bytes < n_pixels * sizeof(float4) && !first) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render_accumulate: no accumulated picture of this size (first call must pass first = 1)");
+    if ((rc = grow(ctx, ctx->acc, n_pixels * sizeof(float4))) != RT_OK) return rc;
+    if (first) RT_HIP_TRY(ctx, hipMemsetAsync(ctx->acc.ptr, 0, n_pixels * sizeof(float4), nullptr));   // Picture acc(width, height): zeros
+    if ((rc = render_enqueue(ctx, bands, static_cast<float4*>(ctx->out_staging.ptr), nullptr)) != RT_OK) return rc;
+    const uint64_t n_floats = n_pixels * 4;
+    hipLaunchKernelGGL(mul_add_kernel, dim3(static_cast<unsigned>((n_floats + 255) / 256)), dim3(256), 0, nullptr, static_cast<float*>(ctx->acc.ptr),
+                       static_cast<const float*>(ctx->out_staging.ptr), weight, n_floats);
+    RT_HIP_TRY(ctx, hipGetLastError());
+    return launch_status(ctx);
+}
+
+int rt_accumulated_rgba8(rt_ctx* ctx, const rt_bands* bands, uint8_t* rgba8_out, float gain) {
+    if (ctx == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    if (rgba8_out == nullptr) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_accumulated_rgba8: output pointer is NULL");
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_pixels = rt_bands_pixel_count(ctx->dev.width, ctx->dev.height, bands);
+    if (n_pixels == 0) return RT_OK;
+    if (ctx->acc.ptr == nullptr || ctx->acc.bytes < n_pixels * sizeof(float4)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_accumulated_rgba8 before rt_render_accumulate");
+    return download_rgba8(ctx, static_cast<const float4*>(ctx->acc.ptr), n_pixels, gain, rgba8_out);
 }
 
 int rt_fetch_stats(rt_ctx* ctx, rt_stats* out) {

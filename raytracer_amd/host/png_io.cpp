@@ -302,7 +302,11 @@ ApngWriter::ApngWriter(std::ostream& out, uint32_t width, uint32_t height, uint3
     emit_chunk(out_, "acTL", actl);
 }
 
-void ApngWriter::frame(const uint8_t* rgba8, uint32_t frame_index, float fps) {
+std::vector<uint8_t> deflate_rgba8(const uint8_t* rgba8, uint32_t width, uint32_t height) { return deflate_frame(rgba8, width, height); }
+
+void ApngWriter::frame(const uint8_t* rgba8, uint32_t frame_index, float fps) { frame_deflated(deflate_frame(rgba8, width_, height_), frame_index, fps); }
+
+void ApngWriter::frame_deflated(const std::vector<uint8_t>& z, uint32_t frame_index, float fps) {
     // sequence numbers: fcTL of frame f is 0 for f == 0 else 2f-1; fdAT of frame f>0 is 2f
     std::vector<uint8_t> fctl;
     put_be32(fctl, frame_index == 0 ? 0 : frame_index * 2 - 1);
@@ -315,7 +319,6 @@ void ApngWriter::frame(const uint8_t* rgba8, uint32_t frame_index, float fps) {
     fctl.push_back(0);   // dispose: none
     fctl.push_back(0);   // blend: source
     emit_chunk(out_, "fcTL", fctl);
-    std::vector<uint8_t> z = deflate_frame(rgba8, width_, height_);
     if (frame_index == 0) {
         emit_chunk(out_, "IDAT", z);
     } else {

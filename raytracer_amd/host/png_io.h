@@ -36,11 +36,17 @@ void quantize_rgba(const float* rgba, uint64_t n_pixels, float gain, uint8_t* ou
 // Still image.
 void write_png(std::ostream& out, const uint8_t* rgba8, uint32_t width, uint32_t height);
 
-// Animation: begin(), then frame() once per frame in order, then end().
+// The compressed scanlines of one frame (Sub filter per row, one zlib compress() at its default level): the costly
+// part of writing a frame, a pure function of the pixels, so frames can be compressed on worker threads while the
+// next ones render and still be appended in order.
+std::vector<uint8_t> deflate_rgba8(const uint8_t* rgba8, uint32_t width, uint32_t height);
+
+// Animation: begin(), then frame() (or frame_deflated() with deflate_rgba8's result) once per frame in order, then end().
 class ApngWriter {
 public:
     ApngWriter(std::ostream& out, uint32_t width, uint32_t height, uint32_t frame_count);
     void frame(const uint8_t* rgba8, uint32_t frame_index, float fps);
+    void frame_deflated(const std::vector<uint8_t>& z, uint32_t frame_index, float fps);
     void end();
 
 private:

@@ -14,9 +14,12 @@
 #include <istream>
 #include <limits>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <sys/stat.h>
 
 #include "png_io.h"
 #include "scene_model.h"
@@ -291,6 +294,58 @@ ObjMesh read_obj(const std::string& path) {
     return mesh;
 }
 
+// ------------------------------------------------------------------ asset cache
+// The reference re-reads and re-decodes every mesh and texture for every frame and sub-frame
+// (src/main.cpp:99,140 call Scene::load afresh); only the keyframed attributes change with t.  Decoded
+// assets are therefore kept per file (invalidated by size or modification time), shared by all loads
+// of the process, including loads made from a prefetch thread.
+struct FileStamp {
+    long long size = -1, mtime_ns = -1;
+    bool operator==(const FileStamp& o) const { return size == o.size && mtime_ns == o.mtime_ns; }
+};
+FileStamp stamp_of(const std::string& path) {
+    struct stat st;
+    FileStamp f;
+    if (::stat(path.c_str(), &st) == 0) {
+        f.size = static_cast<long long>(st.st_size);
+        f.mtime_ns = static_cast<long long>(st.st_mtim.tv_sec) * 1000000000ll + st.st_mtim.tv_nsec;
+    }
+    return f;
+}
+template <typename T>
+class AssetCache {
+public:
+    template <typename Load>
+    std::shared_ptr<const T> get(const std::string& path, Load load) {
+        const FileStamp now = stamp_of(path);
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            auto it = entries_.find(path);
+            if (it != entries_.end() && now.size >= 0 && it->second.stamp == now) return it->second.value;
+        }
+        std::shared_ptr<const T> fresh = std::make_shared<const T>(load(path));   // throws like an uncached load
+        std::lock_guard<std::mutex> lock(mutex_);
+        entries_[path] = {now, fresh};
+        return fresh;
+    }
+
+private:
+    struct Entry {
+        FileStamp stamp;
+        std::shared_ptr<const T> value;
+    };
+    std::mutex mutex_;
+    std::map<std::string, Entry> entries_;
+};
+std::shared_ptr<const ObjMesh> cached_obj(const std::string& path) {
+    static AssetCache<ObjMesh> cache;
+    return cache.get(path, read_obj);
+}
+std::shared_ptr<const ImageRGBA8> cached_png(const std::string& path) {
+    static AssetCache<ImageRGBA8> cache;
+    return cache.get(path, read_png_file);
+}
+
 // ------------------------------------------------------------------ path helper
 // sibling file of the scene file unless absolute (reference src/fspolyfill.h:6-20)
 std::string sibling_path(const std::string& scene_path, const std::string& name) {
@@ -487,9 +542,9 @@ private:
                 scene_.objects.push_back({RT_OBJ_SPHERE, uint32_t(scene_.spheres.size()), add_material(p)});
                 scene_.spheres.push_back(s);
             } else if (at("mesh", TagKind::Open)) {
-                const ObjMesh mesh = read_obj(sibling_path(path_, tag().attr("name")));
+                const std::shared_ptr<const ObjMesh> mesh = cached_obj(sibling_path(path_, tag().attr("name")));
                 const Placement p = placement_element();
-                add_mesh(mesh, p);
+                add_mesh(*mesh, p);
             } else if (at("julia", TagKind::Open)) {
                 rt_julia j{};
                 j.scale = number("scale");
@@ -602,7 +657,8 @@ private:
     int32_t texture_index(const std::string& file) {
         auto it = texture_by_file_.find(file);
         if (it != texture_by_file_.end()) return it->second;
-        const ImageRGBA8 img = read_png_file(file);
+        const std::shared_ptr<const ImageRGBA8> cached = cached_png(file);
+        const ImageRGBA8& img = *cached;
         rt_texture t{};
         t.width = img.width;
         t.height = img.height;

@@ -1,10 +1,31 @@
 #include "tracer_shim.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 
 namespace rta {
 
+namespace {
+// RT_AMD_TIMING=1: seconds spent inside each C-ABI call (stderr at exit; developer aid)
+struct CallTimes {
+    double create = 0, upload = 0, photons = 0, render = 0;
+    bool on = std::getenv("RT_AMD_TIMING") != nullptr;
+    ~CallTimes() {
+        if (on) std::fprintf(stderr, "timing (C ABI): rt_create %.4f s, rt_scene_upload %.4f s, rt_photon_generate %.4f s, rt_render* %.4f s\n", create, upload, photons, render);
+    }
+} g_calls;
+struct CallLap {
+    double& into;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit CallLap(double& d) : into(d) {}
+    ~CallLap() { into += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
+
 GpuSession::GpuSession(int device) {
+    CallLap lap(g_calls.create);
     const int rc = rt_create(&ctx_, device);
     if (rc != RT_OK) throw std::runtime_error(std::string("GPU backend: ") + rt_last_error(nullptr));
 }
@@ -17,17 +38,48 @@ void GpuSession::check(int rc, const char* what) const {
 
 void GpuSession::upload(const SceneModel& scene) {
     const rt_scene_desc d = scene.desc();
-    check(rt_scene_upload(ctx_, &d), "scene upload");
+    {
+        CallLap lap(g_calls.upload);
+        check(rt_scene_upload(ctx_, &d), "scene upload");
+    }
     width_ = scene.camera.width;
     height_ = scene.camera.height;
     uploaded_ = &scene;
 }
 
-void GpuSession::photons() { check(rt_photon_generate(ctx_, nullptr), "photon map"); }
+void GpuSession::photons() {
+    CallLap lap(g_calls.photons);
+    check(rt_photon_generate(ctx_, nullptr), "photon map");
+}
 
 Picture GpuSession::render() {
     Picture p(width_, height_);
+    CallLap lap(g_calls.render);
     check(rt_render(ctx_, nullptr, p.data(), nullptr), "raytrace");
+    return p;
+}
+
+Picture8 GpuSession::render8() {
+    Picture8 p;
+    p.width = width_;
+    p.height = height_;
+    p.pixels.resize(size_t(width_) * height_ * 4);
+    CallLap lap(g_calls.render);
+    check(rt_render_rgba8(ctx_, nullptr, p.pixels.data(), 1.0f, nullptr), "raytrace");
+    return p;
+}
+
+void GpuSession::accumulate(float weight, bool first) {
+    CallLap lap(g_calls.render);
+    check(rt_render_accumulate(ctx_, nullptr, weight, first ? 1 : 0), "raytrace");
+}
+
+Picture8 GpuSession::accumulated8() {
+    Picture8 p;
+    p.width = width_;
+    p.height = height_;
+    p.pixels.resize(size_t(width_) * height_ * 4);
+    check(rt_accumulated_rgba8(ctx_, nullptr, p.pixels.data(), 1.0f), "raytrace");
     return p;
 }
 
@@ -50,5 +102,22 @@ Picture RayTracer::raytrace(const SceneModel& scene) const {
     s.uploaded_ = nullptr;   // the reference reloads the scene for every frame; never reuse stale uploads
     return p;
 }
+
+Picture8 RayTracer::raytrace8(const SceneModel& scene) const {
+    GpuSession& s = GpuSession::process_default();
+    if (s.uploaded_ != &scene) s.upload(scene);
+    Picture8 p = s.render8();
+    s.uploaded_ = nullptr;
+    return p;
+}
+
+void RayTracer::accumulate(const SceneModel& scene, float weight, bool first) const {
+    GpuSession& s = GpuSession::process_default();
+    if (s.uploaded_ != &scene) s.upload(scene);
+    s.accumulate(weight, first);
+    s.uploaded_ = nullptr;
+}
+
+Picture8 RayTracer::accumulated8() const { return GpuSession::process_default().accumulated8(); }
 
 }  // namespace rta

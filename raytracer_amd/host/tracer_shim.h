@@ -38,6 +38,12 @@ private:
     std::vector<float> data_;
 };
 
+// A picture as the writers consume it: RGBA8 after Color::scaleOut (reference src/types.h:274-282).
+struct Picture8 {
+    uint32_t width = 0, height = 0;
+    std::vector<uint8_t> pixels;
+};
+
 // One GPU.  The reference's Scene carries its photon textures inside its objects; here they live on
 // the device inside the session, so a Scene handed to PhotonMapper::generate must be rendered
 // through the same session (the default session is process-wide, like the reference's free calls).
@@ -51,6 +57,9 @@ public:
     void upload(const SceneModel& scene);      // rt_scene_upload
     void photons();                            // rt_photon_generate
     Picture render();                          // rt_render
+    Picture8 render8();                        // rt_render_rgba8
+    void accumulate(float weight, bool first); // rt_render_accumulate
+    Picture8 accumulated8();                   // rt_accumulated_rgba8
     static GpuSession& process_default();
 
 private:
@@ -73,6 +82,14 @@ class RayTracer {
 public:
     // ≙ Picture RayTracer::raytrace(const Scene&) const
     Picture raytrace(const SceneModel& scene) const;
+    // The same followed by what every caller in the reference does with the Picture (src/main.cpp:31,64,105,147),
+    // done on the GPU so that the float picture never crosses the host link:
+    //   raytrace8       raytrace + Color::scaleOut (writePNG / writeAPNGFrame quantise with gain 1)
+    //   accumulate      acc.mulAdd(raytrace(scene), weight) with acc zeroed when `first`; acc stays on the device
+    //   accumulated8    scaleOut of acc
+    Picture8 raytrace8(const SceneModel& scene) const;
+    void accumulate(const SceneModel& scene, float weight, bool first) const;
+    Picture8 accumulated8() const;
 };
 
 }  // namespace rta
