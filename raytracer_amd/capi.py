@@ -213,8 +213,9 @@ def apng_write(path, frames_rgba8, fps):
     handle = host_lib().rth_apng_begin(os.fsencode(path), w, h, len(frames), err, len(err))
     if not handle:
         raise SceneError(err.value.decode())
+    fps_of = fps if isinstance(fps, (list, tuple)) else [fps] * len(frames)
     for i, f in enumerate(frames):
-        host_lib().rth_apng_frame(handle, f.ctypes.data, i, fps)
+        host_lib().rth_apng_frame(handle, f.ctypes.data, i, fps_of[i])
     host_lib().rth_apng_end(handle)
 
 

@@ -10,8 +10,8 @@ pass whole on the rank that renders the frame.
 
   stills                 8-row bands of the image, interleaved over the ranks (per-pixel cost is very
                          uneven on Julia scenes; the reference hands out single rows dynamically,
-                         src/raytracer.cpp:48-53); photon pass split over the ranks + all-reduce when
-                         it is large enough to pay (SPLIT_PHOTON_MIN_STEPS, or RT_SPLIT_PHOTONS=0/1)
+                         src/raytracer.cpp:48-53); with RT_SPLIT_PHOTONS=1 the photon pass is split over the
+                         ranks + all-reduce (equal to rounding only, hence opt-in)
   still + motion blur    sub-frames round-robin over the ranks
   animation              frames round-robin over the ranks, RGBA8 frames gathered
   animation + blur       (frame, sub-frame) pairs round-robin over the ranks
@@ -152,13 +152,13 @@ def motion_blur_units(path, info, load=capi.Scene):
 # ---------------------------------------------------------------------------------- the loops
 
 def split_photon_pass(scene, world):
-    """Whether the ranks share one photon pass (stills only).  RT_SPLIT_PHOTONS=0/1 overrides."""
+    """Whether the ranks share one photon pass (stills only).  Opt-in (RT_SPLIT_PHOTONS=1): the sum of the ranks'
+    partial textures differs from the reference's sequential sum in the last float bits, so the default keeps the
+    pass whole on every rank and the PNG identical to the one-GPU file; SPLIT_PHOTON_MIN_STEPS is the size from which
+    the split pays when asked for."""
     if world <= 1 or scene.desc.photon_steps <= 0:
         return False
-    forced = os.environ.get("RT_SPLIT_PHOTONS")
-    if forced is not None:
-        return forced not in ("", "0")
-    return scene.desc.photon_steps >= SPLIT_PHOTON_MIN_STEPS
+    return os.environ.get("RT_SPLIT_PHOTONS", "0") not in ("", "0") and scene.desc.photon_steps >= SPLIT_PHOTON_MIN_STEPS
 
 
 def render_still(renderer, scene):
@@ -190,31 +190,116 @@ def render_still(renderer, scene):
     return full
 
 
-def render_units(renderer, path, units, consume):
-    """Renders `units` [(key..., t, ...)] round-robin over the ranks, one gather per round; on rank 0
-    calls consume(unit, picture) in unit order."""
+def render_units_sequential(renderer, path, units, consume):
+    """Lock-step form of render_units (parse, render, blocking gather, consume): kept as the reference the
+    pipelined form is tested against (RT_DRIVER_SEQUENTIAL=1 selects it)."""
     rank, world = world_info()
     rounds = math.ceil(len(units) / world)
-    shape = None
     for i in range(rounds):
         mine = i * world + rank
-        pic = None
         if mine < len(units):
-            scene = capi.Scene(path, units[mine][2])
-            pic = renderer.render(scene)
-            shape = pic.shape
-        if pic is None:
-            # a rank without a unit in the last round still takes part in the gather
-            probe = capi.Scene(path, units[0][2])
-            pic = torch.zeros((probe.width * probe.height, 4), dtype=torch.float32,
-                              device=getattr(renderer, "device", torch.device("cpu")))
+            pic = renderer.render(capi.Scene(path, units[mine][2]))
+        else:
+            probe = capi.Scene(path, units[0][2])      # a rank without a unit in the last round still takes part
+            pic = torch.zeros((probe.width * probe.height, 4), dtype=torch.float32, device=getattr(renderer, "device", torch.device("cpu")))
         pics = gather_to_root(pic)
         if rank == 0:
             for r in range(world):
                 j = i * world + r
                 if j < len(units):
                     consume(units[j], pics[r])
-    return shape
+
+
+def render_units(renderer, path, units, consume, payload=None, timing=None):
+    """Renders `units` [(key..., t, ...)] round-robin over the ranks; on rank 0 calls consume(unit, picture) in unit
+    order.  Pipelined: the scene file of the next unit is parsed on a host thread while this one renders, the gather
+    of round i (async, two buffers) runs while round i+1 renders, and rank 0 consumes round i-1 meanwhile.
+    `payload(picture)` is what travels (e.g. the picture quantised to RGBA8 on the rank that rendered it: a quarter
+    of the bytes); default the float picture.  `timing` (dict) receives this rank's GPU-busy seconds."""
+    if os.environ.get("RT_DRIVER_SEQUENTIAL", "0") not in ("", "0"):
+        if payload is None:
+            return render_units_sequential(renderer, path, units, consume)
+        return render_units_sequential(renderer, path, units, lambda u, pic: consume(u, payload(pic)))
+    from concurrent.futures import ThreadPoolExecutor
+    rank, world = world_info()
+    rounds = math.ceil(len(units) / world)
+    device = getattr(renderer, "device", torch.device("cpu"))
+    on_gpu = device.type == "cuda"
+    payload = payload or (lambda pic: pic)
+    bufs, gathered, pending = [None, None], [None, None], [None, None]
+    busy = []
+
+    def load(i):
+        mine = i * world + rank
+        return capi.Scene(path, units[mine][2]) if mine < len(units) else None
+
+    def consume_round(i):
+        if pending[i % 2] is not None:
+            pending[i % 2].wait()
+            pending[i % 2] = None
+        if rank == 0:
+            pics = gathered[i % 2] if world > 1 else [bufs[i % 2]]
+            for r in range(world):
+                j = i * world + r
+                if j < len(units):
+                    consume(units[j], pics[r])
+
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        nxt = pool.submit(load, 0) if rounds else None
+        for i in range(rounds):
+            scene = nxt.result()
+            nxt = pool.submit(load, i + 1) if i + 1 < rounds else None
+            b = i % 2
+            if scene is not None:
+                if on_gpu and timing is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                out = payload(renderer.render(scene))
+                if on_gpu and timing is not None:
+                    e1.record()
+                    busy.append((e0, e1))
+            else:
+                # a rank without a unit in the last round still takes part in the gather
+                probe = capi.Scene(path, units[0][2])
+                out = payload(torch.zeros((probe.width * probe.height, 4), dtype=torch.float32, device=device))
+            if i >= 2:
+                consume_round(i - 2)               # frees gathered[b]; round i is already on the GPU's queue
+            bufs[b] = out
+            if world > 1:
+                if rank == 0 and (gathered[b] is None or gathered[b][0].shape != out.shape or gathered[b][0].dtype != out.dtype):
+                    gathered[b] = [torch.empty_like(out) for _ in range(world)]
+                pending[b] = dist.gather(out, gathered[b] if rank == 0 else None, dst=0, async_op=True)
+        for i in range(max(0, rounds - 2), rounds):
+            consume_round(i)
+    if timing is not None:
+        if on_gpu:
+            torch.cuda.synchronize()
+        timing["gpu_busy_s"] = timing.get("gpu_busy_s", 0.0) + sum(a.elapsed_time(b) for a, b in busy) * 1e-3
+
+
+class HostFrames:
+    """RGBA8 frames on their way to the host: on a GPU each is copied into pinned memory on a side stream, so the
+    rank that writes the file never stalls its render queue on a download; frames() waits for them all."""
+
+    def __init__(self, device):
+        self.items = []
+        self.stream = torch.cuda.Stream(device) if device.type == "cuda" else None
+
+    def add(self, q):
+        if self.stream is None:
+            self.items.append(q.cpu())
+            return
+        host = torch.empty(q.shape, dtype=q.dtype, pin_memory=True)
+        self.stream.wait_event(torch.cuda.current_stream().record_event())
+        with torch.cuda.stream(self.stream):
+            host.copy_(q, non_blocking=True)
+        q.record_stream(self.stream)
+        self.items.append(host)
+
+    def frames(self):
+        if self.stream is not None:
+            self.stream.synchronize()
+        return [t.numpy() for t in self.items]
 
 
 def render_scene_file(renderer, path, out_path=None):
@@ -229,20 +314,21 @@ def render_scene_file(renderer, path, out_path=None):
     out_path = out_path or info.output_file.decode()
     h, w = probe.height, probe.width
     animated = info.frames > 1 and info.still_time == f32(capi.FLT_MAX)
-    frames8 = []
+    host = HostFrames(getattr(renderer, "device", torch.device("cpu")))
 
     def to_host8(rgba):
-        q = renderer.quantize(rgba.reshape(h, w, 4).contiguous())
-        return q.cpu().numpy()
+        host.add(renderer.quantize(rgba.reshape(h, w, 4).contiguous()))
 
     if not animated and info.sub_frames <= 1:
         scene = capi.Scene(path, float(still_time(info)))
         full = render_still(renderer, scene)
         if rank == 0:
-            frames8.append(to_host8(full))
+            to_host8(full)
     elif info.sub_frames <= 1:
         units = [(f, 0, float(f32(f) / f32(info.frames - 1))) for f in range(info.frames)]
-        render_units(renderer, path, units, lambda u, pic: frames8.append(to_host8(pic)))
+        # every rank quantises its own frame (Color::scaleOut): RGBA8 travels, a quarter of the float picture
+        render_units(renderer, path, units, lambda u, q: host.add(q.reshape(h, w, 4)),
+                     payload=lambda pic: renderer.quantize(pic.reshape(h, w, 4).contiguous()))
     else:
         units = motion_blur_units(path, info)
         state = {"acc": None, "frame": 0}
@@ -253,14 +339,20 @@ def render_scene_file(renderer, path, out_path=None):
                 state["acc"] = torch.zeros_like(pic)
             renderer.mul_add(state["acc"], pic, weight)      # Picture::mulAdd, in sub-frame order
             if sub == k - 1:
-                frames8.append(to_host8(state["acc"]))
+                to_host8(state["acc"])
                 state["acc"] = None
 
         render_units(renderer, path, units, consume)
+    frames8 = host.frames()
     if rank != 0:
         return None
     if animated:
-        capi.apng_write(out_path, frames8, info.fps)
+        if info.sub_frames <= 1:
+            # writeAPNGFrame(..., scene.fps()) with the frame's own scene (src/main.cpp:105): fps may be keyframed
+            fps = [capi.Scene(path, u[2]).info.fps for u in units]
+        else:
+            fps = [info.fps] * len(frames8)      # renderVideoMotionBlur uses origScene.fps() (src/main.cpp:152)
+        capi.apng_write(out_path, frames8, fps)
     else:
         capi.png_write(out_path, frames8[0])
     return frames8

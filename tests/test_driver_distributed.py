@@ -111,24 +111,40 @@ def test_two_ranks_share_one_photon_pass(tmp_path):
     assert len(got) == len(want) == 1
     d = oracle_lib.image_diff(got[0], want[0])
     assert d["max"] <= 1 and d["frac_gt0"] < 1e-3, d
-    # and the policy: small passes stay whole on every rank, large ones are shared
-    assert not driver.split_photon_pass(sc, 2) and not driver.split_photon_pass(sc, 1)
+
+
+def test_photon_split_is_opt_in(monkeypatch):
+    """The default keeps a still's photon pass whole on every rank (N-GPU PNG == 1-GPU PNG); RT_SPLIT_PHOTONS=1
+    shares passes that are large enough to pay."""
     big = capi.Scene(scene_path("examples3/103_caustic_animation.xml"), 0.0)
+    small = capi.Scene(scene_path("examples3/103_caustic_steps200.xml"), 0.0)
+    monkeypatch.delenv("RT_SPLIT_PHOTONS", raising=False)
+    assert not driver.split_photon_pass(big, 8) and not driver.split_photon_pass(big, 1)
+    monkeypatch.setenv("RT_SPLIT_PHOTONS", "1")
     assert driver.split_photon_pass(big, 8) and not driver.split_photon_pass(big, 1)
+    assert small.desc.photon_steps < driver.SPLIT_PHOTON_MIN_STEPS
+    assert not driver.split_photon_pass(small, 8)
 
 
-def test_schedules():
-    # interleaved bands cover every row exactly once, whatever the world size
-    for h in (1, 7, 8, 600, 2160):
-        for world in (1, 2, 3, 8):
-            rows = sorted(y for r in range(world) for y in driver.band_rows_of(h, r, world))
-            assert rows == list(range(h))
-    # frame/sub-frame times of the shipped animation variant (reference src/main.cpp:140)
-    path = scene_path("examples3/103_caustic_animation_mb8.xml")
-    info = capi.Scene(path, 0.0).info
-    units = driver.motion_blur_units(path, info)
-    assert len(units) == 20 * 8
-    f, s, t, wgt, k = units[8 * 3 + 5]
-    assert (f, s, k) == (3, 5, 8)
-    assert t == float((np.float32(3) + np.float32(5) / np.float32(7)) / np.float32(20))
-    assert wgt == float(np.float32(1) / np.float32(8))
+@pytest.mark.parametrize("tags", ['<animation length="0.5" fps="6;12"/>', '<animation length="0.4" fps="5"/><motionblur subframes="2;4"/>'])
+def test_pipelined_driver_equals_lock_step(tmp_path, tags):
+    """render_units overlaps parse, render, gather and consume; the frames and the file must be those of the
+    lock-step loop.  The first scene animates fps: each frame's delay is its own scene's (src/main.cpp:105)."""
+    scene = small_scene(tmp_path, tags)
+    a, png_a = run_two_ranks(scene, tmp_path)
+    raw_a = open(png_a, "rb").read()
+    b, png_b = run_two_ranks(scene, tmp_path, RT_DRIVER_SEQUENTIAL="1")
+    assert np.array_equal(a, b) and raw_a == open(png_b, "rb").read()
+    if "6;12" in tags:
+        # fcTL chunks carry delay_num/delay_den = 1/fps of each frame's own scene
+        import struct
+        dens, pos = [], 8
+        while pos < len(raw_a):
+            n, kind = struct.unpack(">I4s", raw_a[pos:pos + 8])
+            if kind == b"fcTL":
+                dens.append(struct.unpack(">HH", raw_a[pos + 8 + 20:pos + 8 + 24]))
+            pos += 12 + n
+        info = capi.Scene(scene, 0.0).info
+        want = [capi.Scene(scene, float(np.float32(f) / np.float32(info.frames - 1))).info.fps for f in range(info.frames)]
+        assert len(dens) == info.frames and len(set(want)) > 1
+        assert dens == [(int(np.float32(1000.0) / np.float32(x)), 1000) for x in want], (dens, want)
