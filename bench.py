@@ -11,6 +11,17 @@ largest single-GPU configuration.  `--workload` selects another config for devel
 N > 1: frames are independent units: every rank renders its own full frame per step and
 rank 0 collects the RGBA8 frames ("scaling": "weak").  value = rays of all ranks / max-over-ranks time.
 
+The north star's two splits are measured at every N through the product driver (raytracer_amd/driver.py)
+and reported under "extra" (fixed total work, i.e. strong scaling):
+  c4_tiles   examples3/101_julia_shiny.xml, 8-row bands interleaved over the ranks (driver.render_still),
+             float bands gathered to rank 0 and quantised there
+  c5_frames  examples3/103_caustic_animation.xml, 20 frames round-robin over the ranks (driver.render_units)
+  c5mb8      examples3/103_caustic_animation_mb8.xml, 160 (frame, sub-frame) units round-robin, motion blur
+             accumulated on rank 0 in sub-frame order
+each with sec/frame, rays/s and every rank's GPU-busy fraction (GPU time of its render calls / wall time).
+Those timings cover parse + upload + photon pass + trace + gather + quantise + download of the RGBA8 frames
+to the host; the PNG/APNG encode is not in them.  `--workload c5mb` makes the 160-unit file the main line.
+
 Ray counts come from a counters-enabled launch of the same kernels outside the timed region (the
 counters are pinned to the oracle's by tests/test_gpu_parity.py).
 """
@@ -41,29 +52,57 @@ FLOPS = {"triangle_tests": 29, "sphere_tests": 59, "shaded_hits": 64, "phong_lig
          "julia_steps": 11, "julia_normals": 36, "julia_queries": 30, "photon_segments": 37,
          "bvh_node_visits": 21}   # ours, not the reference's: slab test of one node (6 sub, 6 mul, 6 min/max, 3 compares)
 PEAK_FP32_TFLOPS = 157.3   # MI355X FP32 vector peak (MI355X_MICROARCH.md); assumes packed FMA
-ISSUE_CEILING_TFLOPS = 39.3   # 256 CUs x 64 lanes x 2.4 GHz: one non-fused mul or add per lane and clock
+# Lane-operations per second when every SIMD issues one plain (non-packed, non-fused) FP32 instruction as fast as it
+# can: 256 CUs x 4 SIMDs x 32 lanes per clock x 2.4 GHz (a wave64 instruction takes 2 clocks; tools/valu_rate.hip
+# measures 2.4-2.9 for v_mul/v_add/v_fma, 4.3-5 for packed, v_cmp, v_max/v_min and f64, 8 for rcp/sqrt/exp).
+ISSUE_CEILING_LANE_OPS = 256 * 4 * 32 * 2.4e9
+
+
+def pmc_record(workload):
+    """The committed PMC passes of this workload (profiles/traffic.json, made by tools/traffic_json.py from separate
+    rocprofv3 --pmc runs of this bench; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(workload, {})
+    except (OSError, ValueError):
+        return {}
 
 
 def measured_traffic(workload):
-    """HBM bytes per trace_kernel launch from the committed PMC passes (profiles/traffic.json, made by
-    tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this bench; FETCH_SIZE doubled
-    as MI355X_MICROARCH.md prescribes for gfx950).  None when no pass exists for the workload."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
+    """HBM bytes per launch of the dominant kernel from the PMC passes; None when no pass exists."""
+    return pmc_record(workload).get("hbm_bytes_per_launch")
+
+
+def executed_valu(workload, kernel_ms):
+    """What the kernel EXECUTED (not the algorithmic count): SQ_INSTS_VALU x mean active lanes per instruction from
+    the committed PMC pass, over the kernel time measured live, against the plain-FP32 issue ceiling."""
+    rec = pmc_record(workload)
+    insts, lanes = rec.get("valu_wave_instructions"), rec.get("active_lanes_per_valu_instruction")
+    if not insts or not lanes:
         return None
+    rate = insts * lanes / (kernel_ms * 1e-3)
+    return {"lane_ops_per_s": rate, "frac_of_issue_ceiling": rate / ISSUE_CEILING_LANE_OPS,
+            "issue_ceiling_lane_ops_per_s": ISSUE_CEILING_LANE_OPS, "valu_wave_instructions": insts, "active_lanes": lanes,
+            "note": "SQ_INSTS_VALU x active lanes (profiles/traffic.json) / live kernel time; ceiling = 256 CUs x 4 SIMDs x "
+                    "32 lanes/clk x 2.4 GHz, which only plain f32 mul/add/fma/mov reach (tools/valu_rate.hip)"}
 
 
 def algorithmic_flops(stats_dict):
     return float(sum(stats_dict.get(k, 0) * w for k, w in FLOPS.items()))
 
 
+def host_cores():
+    """Threads for the CPU legs: the GPU box gives one GPU's job 16 of the machine's cores (OMP_NUM_THREADS is set to
+    that share there); os.cpu_count() shows the whole machine and is reported beside it."""
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or 16
+    return max(1, min(share, os.cpu_count() or 1))
+
+
 def cpu_baseline(scene, n_rays_frame):
     """The oracle (CPU restatement, "port") timed on this box's host cores on the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
-    cores = min(16, os.cpu_count() or 1)
+    cores = host_cores()
     cam = scene.desc.camera
     # bounded sample: every k-th row of the frame, repeated until about 10 s of CPU time (cores x wall)
     step = 1
@@ -82,30 +121,34 @@ def cpu_baseline(scene, n_rays_frame):
         reps += 1
     dt = time.time() - t0 + t_photon * reps
     rays += (photons.stats.photon_segments if photons else 0) * reps
-    return {"value": rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+    return {"value": rays / dt, "unit": "rays/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
             "sample": "oracle/liboracle.so (CPU restatement, pinned bit-exact to the reference's O-strict build), every %d-th row "
                       "of the frame (%d rows) x %d repetitions%s, %.2f s wall on %d threads" % (
                 step, (cam.height + step - 1) // step, reps, " + serial photon pass" if photons else "", dt, cores)}
 
 
-def cpu_reference(scene_path, n_rays_frame):
+def cpu_reference(scene_path, n_rays_frame, still_at=None):
     """The reference's own program (oracle/_ref/raytracer_ostrict: its unmodified sources compiled by
     oracle/Makefile, g++ -O2) on the same scene file with threads = host cores; time = its own
-    'Finished in' line (trace + PNG encode, src/main.cpp:23-35).  None where the binary is absent."""
+    'Finished in' line (trace + PNG encode, src/main.cpp:23-35).  `still_at` renders one frame of an animated
+    file (a <still time=…/> tag, src/sceneparser.cpp).  None where the binary is absent."""
     import re
     import subprocess
     import tempfile
     exe = os.path.join(ROOT, "oracle", "_ref", "raytracer_ostrict")
     if not os.path.exists(exe):
         return None
-    cores = min(16, os.cpu_count() or 1)
+    cores = host_cores()
     try:
         with tempfile.TemporaryDirectory() as tmp:
             src_dir = os.path.dirname(scene_path)
             for name in os.listdir(src_dir):
-                os.symlink(os.path.join(src_dir, name), os.path.join(tmp, name + ".lnk") if name == os.path.basename(scene_path) else os.path.join(tmp, name))
+                if name != os.path.basename(scene_path):
+                    os.symlink(os.path.join(src_dir, name), os.path.join(tmp, name))
             xml = open(scene_path).read()
             xml = re.sub(r"<scene\b", '<scene threads="%d"' % cores, re.sub(r'\sthreads="[^"]*"', "", xml), count=1)
+            if still_at is not None:
+                xml = re.sub(r"(<animation\b[^>]*/>)", r'\1<still time="%r"/>' % still_at, xml, count=1)
             path = os.path.join(tmp, "bench_scene.xml")
             with open(path, "w") as f:
                 f.write(xml)
@@ -114,11 +157,141 @@ def cpu_reference(scene_path, n_rays_frame):
         if not m:
             return None
         sec = float(m.group(1))
-        return {"value": n_rays_frame / sec, "unit": "rays/s", "cores": cores, "kind": "reference",
-                "sample": "oracle/_ref/raytracer_ostrict (reference sources, g++ -O2 -pthread), whole frame, threads=%d, its own "
-                          "'Finished in' timer = %.2f s (trace + PNG encode); rays = the nearest-hit formulation's count" % (cores, sec)}
+        return {"value": n_rays_frame / sec, "unit": "rays/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "reference",
+                "sec_per_frame": sec,
+                "sample": "oracle/_ref/raytracer_ostrict (reference sources, g++ -O2 -pthread; the author's -Ofast build is not "
+                          "bit-reproducible and is not used), whole frame%s, threads=%d, its own 'Finished in' timer = %.2f s "
+                          "(%strace + PNG encode); rays = the nearest-hit formulation's count" % (
+                              "" if still_at is None else " at <still time=%r>" % still_at, cores, sec, "photon pass + " if still_at is not None else "")}
     except Exception:   # noqa: BLE001 - a missing or failing reference binary must not break the bench line
         return None
+
+
+# ------------------------------------------------------------------------- the north star's splits, through the driver
+
+def count_rays(ctx, capi, path, times):
+    """(rays, algorithmic flops) of the units at `times` from counters-enabled launches; rays = primary + secondary +
+    shadow + photon segments."""
+    import torch
+    ctx.set_option(capi.RT_OPT_COLLECT_STATS, 1)
+    total, flops = 0, 0.0
+    for t in times:
+        scene = capi.Scene(path, float(t))
+        ctx.upload(scene)
+        d = ctx.photon_generate().as_dict() if scene.desc.photon_steps > 0 else {}
+        out = torch.empty((scene.width * scene.height, 4), dtype=torch.float32, device="cuda")
+        ctx.render_device(out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        r = ctx.fetch_stats().as_dict()
+        total += r["primary_rays"] + r["secondary_rays"] + r["shadow_rays"] + d.get("photon_segments", 0)
+        flops += algorithmic_flops({k: v + d.get(k, 0) for k, v in r.items() if k != "kernel_ms"})
+    ctx.set_option(capi.RT_OPT_COLLECT_STATS, 0)
+    return total, flops
+
+
+def timed_job(job, renderer, reps, warmup, world, dev):
+    """Runs job() `warmup` + `reps` times; returns (max-over-ranks wall seconds of the `reps`, [busy fraction per rank])."""
+    import torch
+    import torch.distributed as dist
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        job()
+    fence()
+    renderer.busy_events = []
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        job()
+    fence()
+    elapsed = time.perf_counter() - t0
+    busy = renderer.busy_seconds()
+    renderer.busy_events = None
+    both = torch.tensor([elapsed, busy], dtype=torch.float64, device=dev)
+    if world > 1:
+        rows = [torch.empty_like(both) for _ in range(world)]
+        dist.all_gather(rows, both)
+    else:
+        rows = [both]
+    rows = [r.tolist() for r in rows]
+    wall = max(r[0] for r in rows)
+    return wall, [round(r[1] / wall, 4) for r in rows]
+
+
+def split_measurements(which, renderer, ctx, capi, driver, world, rank, dev, reps, warmup):
+    """The north star's splits (module docstring) at this world size; dict of results on every rank."""
+    import torch
+    import torch.distributed as dist
+    f32 = np.float32
+    out = {}
+
+    def shared(x):      # rank 0's count, known to all
+        if world == 1:
+            return x
+        t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+        dist.broadcast(t, 0)
+        return float(t.item())
+
+    if "c4_tiles" in which:
+        path = os.path.join(ROOT, "scenes", "examples3", "101_julia_shiny.xml")
+        scene = capi.Scene(path, 0.0)
+        rays = shared(count_rays(ctx, capi, path, [0.0])[0] if rank == 0 else 0)
+        host = driver.HostFrames(dev)
+
+        def job():
+            full = driver.render_still(renderer, scene)
+            if rank == 0:
+                host.items.clear()
+                host.add(renderer.quantize(full))
+                host.frames()
+        wall, busy = timed_job(job, renderer, reps, warmup, world, dev)
+        out["c4_tiles"] = {"scene": "examples3/101_julia_shiny.xml", "split": "8-row bands interleaved over %d rank(s), float bands gathered to rank 0" % world,
+                           "scaling": "strong", "frames": reps, "sec_per_frame": wall / reps, "rays_per_frame": rays,
+                           "rays_per_s": rays * reps / wall, "gpu_busy_frac_per_rank": busy}
+    for key, name in (("c5_frames", "103_caustic_animation.xml"), ("c5mb8", "103_caustic_animation_mb8.xml")):
+        if key not in which:
+            continue
+        path = os.path.join(ROOT, "scenes", "examples3", name)
+        info = capi.Scene(path, 0.0).info
+        if info.sub_frames > 1:
+            times = [u[2] for u in driver.motion_blur_units(path, info)]
+        else:
+            times = [float(f32(f) / f32(info.frames - 1)) for f in range(info.frames)]
+        rays, flops = count_rays(ctx, capi, path, times) if rank == 0 else (0, 0.0)
+        rays, flops = shared(rays), shared(flops)
+        wall, busy = timed_job(lambda: driver.render_frames(renderer, path), renderer, reps, warmup, world, dev)
+        out[key] = {"scene": "examples3/" + name, "split": "%d units round-robin over %d rank(s), pipelined gathers to rank 0" % (len(times), world),
+                    "scaling": "strong", "repetitions": reps, "units": len(times), "frames": info.frames,
+                    "units_per_s": len(times) * reps / wall, "sec_per_frame": wall / reps / info.frames, "sec_per_file": wall / reps,
+                    "rays_per_file": rays, "flops_per_file": flops, "rays_per_s": rays * reps / wall, "gpu_busy_frac_per_rank": busy}
+    return out
+
+
+def units_line(args, capi, driver, world, rank, local_rank, dev):
+    """--workload c5mb: a step is the whole 160-unit file through driver.render_frames (strong scaling over N)."""
+    import torch.distributed as dist
+    renderer = driver.HipRenderer(local_rank)
+    res = split_measurements(("c5mb8",), renderer, renderer.ctx, capi, driver, world, rank, dev, args.steps, args.warmup)["c5mb8"]
+    if rank == 0:
+        line = {"metric": "rays/sec", "value": res["rays_per_s"], "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": res["sec_per_file"] * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                "data": "scene-file",
+                "config": {"workload": "C5 examples3/103_caustic_animation_mb8.xml: 20 frames x 8 motion-blur sub-frames = 160 units (photon pass + render each)",
+                           "scene": res["scene"], "units": res["units"], "units_per_s": res["units_per_s"], "sec_per_frame": res["sec_per_frame"],
+                           "rays_per_file": res["rays_per_file"], "gpu_busy_frac_per_rank": res["gpu_busy_frac_per_rank"], "parallelism": res["split"]},
+                "roofline": None}
+        busy_s = sum(res["gpu_busy_frac_per_rank"]) * res["sec_per_file"] * args.steps      # GPU seconds of all ranks
+        achieved = res["flops_per_file"] * args.steps / busy_s / 1e12
+        line["roofline"] = {"bound": "valu", "kernel": "trace_kernel (+ photon_kernel, ordered photon sum)", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
+                            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                            "note": "algorithmic flops of the 160 units / GPU-busy time of the render calls (upload + photon pass + trace per unit, "
+                                    "event pairs on the render stream); per-kernel figures are on the c5 line"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -126,14 +299,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["mesh"])
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["mesh", "c5mb"])
+    ap.add_argument("--no-extra", action="store_true", help="skip the C4-tiles / C5-frames measurements under 'extra'")
+    ap.add_argument("--extra-reps", type=int, default=3)
     ap.add_argument("--bvh-min", type=int, default=None, help="developer: RT_OPT_BVH_MIN_TRIANGLES before the upload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from raytracer_amd import capi
+    from raytracer_amd import capi, driver
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -143,6 +318,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
+
+    if args.workload == "c5mb":
+        return units_line(args, capi, driver, world, rank, local_rank, dev)
 
     if args.workload == "mesh":     # developer workload for the BVH: 104k-triangle synthetic mesh, 1920x1080
         import pathlib
@@ -239,28 +417,44 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
     ctx.launch_status()      # raises if the Julia kernel's watchdog abandoned the last launch
 
+    extra = None
+    if args.workload == "c2" and not args.no_extra:
+        extra = split_measurements(("c4_tiles", "c5_frames", "c5mb8"), driver.HipRenderer(local_rank), ctx, capi, driver,
+                                   world, rank, dev, args.extra_reps, 1)
+        extra["c4_sec_per_frame"] = extra["c4_tiles"]["sec_per_frame"]
+        extra["c5_sec_per_frame"] = extra["c5_frames"]["sec_per_frame"]
+        extra["note"] = ("through raytracer_amd/driver.py at this world size, fixed total work: parse + upload + photon pass + trace + "
+                         "gather + quantise + RGBA8 download; PNG/APNG encode excluded")
+
     if rank == 0:
         value = rays_per_step * world * args.steps / elapsed
         achieved = flops_per_step / (kernel_ms * 1e-3) / 1e12
         line = {
             "metric": "rays/sec", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "scene-file",
             "config": {"workload": label, "scene": rel, "t": t, "rays_per_frame": rays_per_step,
                        "frames_per_step": world, "sec_per_frame": elapsed / args.steps,
                        "parallelism": "frames sharded over ranks, RGBA8 frames gathered to rank 0 over RCCL (gather of a step overlaps the next step's render; all gathers complete inside the timed region)" if world > 1 else "1 GPU"},
             "roofline": {"bound": "valu", "kernel": "trace_julia_kernel" if scene.desc.n_julias > 0 else "trace_kernel", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": measured_traffic(args.workload),
-                         "frac_of_unfused_issue_ceiling": achieved / ISSUE_CEILING_TFLOPS,
+                         "executed_valu": executed_valu(args.workload, kernel_ms),
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops_per_step,
                          "note": "FP32 VALU bound (no HBM or MFMA roofline applies: scene is KBs, nothing is a contraction); " + flops_note + "; see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene, rays_per_step)
-            if args.workload != "mesh" and not has_photons:
-                ref = cpu_reference(os.path.join(ROOT, "scenes", rel), rays_per_step)
+            if args.workload != "mesh":
+                ref = cpu_reference(os.path.join(ROOT, "scenes", rel), rays_per_step, still_at=t if has_photons else None)
                 if ref is not None:
                     line["cpu_reference"] = ref
+        if extra is not None:
+            if world == 1 and not args.no_cpu_baseline:
+                c5 = os.path.join(ROOT, "scenes", "examples3", "103_caustic_animation.xml")
+                ref = cpu_reference(c5, extra["c5_frames"]["rays_per_file"] / extra["c5_frames"]["frames"], still_at=0.5)
+                if ref is not None:
+                    extra["c5_cpu_reference"] = ref
+            line["extra"] = extra
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

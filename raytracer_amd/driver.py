@@ -48,6 +48,14 @@ class HipRenderer:
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
         self.ctx = capi.Context(device_index)
+        self.busy_events = None      # a list: render() then brackets its GPU work with event pairs (bench.py)
+
+    def busy_seconds(self):
+        """GPU time of the render() calls since busy_events was set to a list; clears the list."""
+        torch.cuda.synchronize()
+        total = sum(a.elapsed_time(b) for a, b in self.busy_events) * 1e-3
+        self.busy_events = []
+        return total
 
     def _photon_pass(self, enqueue):
         """Enqueues a photon pass; if it outgrew the record buffer of the ordered sum (the library has resized it
@@ -70,6 +78,9 @@ class HipRenderer:
 
     def render(self, scene, bands=None, photons_ready=False):
         stream = torch.cuda.current_stream().cuda_stream
+        if self.busy_events is not None:
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record()
         if not photons_ready:      # (an upload clears the photon textures)
             self.ctx.upload(scene)
             if scene.desc.photon_steps > 0:
@@ -80,6 +91,9 @@ class HipRenderer:
             self.ctx.render_device(out.data_ptr(), stream, bands)
             if scene.desc.n_julias > 0:
                 self.ctx.launch_status()     # an abandoned Julia launch must not reach the gather as a picture
+        if self.busy_events is not None:
+            pair[1].record()
+            self.busy_events.append(pair)
         return out
 
     def mul_add(self, acc, src, factor):
@@ -210,12 +224,12 @@ def render_units_sequential(renderer, path, units, consume):
                     consume(units[j], pics[r])
 
 
-def render_units(renderer, path, units, consume, payload=None, timing=None):
+def render_units(renderer, path, units, consume, payload=None):
     """Renders `units` [(key..., t, ...)] round-robin over the ranks; on rank 0 calls consume(unit, picture) in unit
     order.  Pipelined: the scene file of the next unit is parsed on a host thread while this one renders, the gather
     of round i (async, two buffers) runs while round i+1 renders, and rank 0 consumes round i-1 meanwhile.
     `payload(picture)` is what travels (e.g. the picture quantised to RGBA8 on the rank that rendered it: a quarter
-    of the bytes); default the float picture.  `timing` (dict) receives this rank's GPU-busy seconds."""
+    of the bytes); default the float picture."""
     if os.environ.get("RT_DRIVER_SEQUENTIAL", "0") not in ("", "0"):
         if payload is None:
             return render_units_sequential(renderer, path, units, consume)
@@ -224,10 +238,8 @@ def render_units(renderer, path, units, consume, payload=None, timing=None):
     rank, world = world_info()
     rounds = math.ceil(len(units) / world)
     device = getattr(renderer, "device", torch.device("cpu"))
-    on_gpu = device.type == "cuda"
     payload = payload or (lambda pic: pic)
     bufs, gathered, pending = [None, None], [None, None], [None, None]
-    busy = []
 
     def load(i):
         mine = i * world + rank
@@ -251,13 +263,7 @@ def render_units(renderer, path, units, consume, payload=None, timing=None):
             nxt = pool.submit(load, i + 1) if i + 1 < rounds else None
             b = i % 2
             if scene is not None:
-                if on_gpu and timing is not None:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
                 out = payload(renderer.render(scene))
-                if on_gpu and timing is not None:
-                    e1.record()
-                    busy.append((e0, e1))
             else:
                 # a rank without a unit in the last round still takes part in the gather
                 probe = capi.Scene(path, units[0][2])
@@ -271,10 +277,6 @@ def render_units(renderer, path, units, consume, payload=None, timing=None):
                 pending[b] = dist.gather(out, gathered[b] if rank == 0 else None, dst=0, async_op=True)
         for i in range(max(0, rounds - 2), rounds):
             consume_round(i)
-    if timing is not None:
-        if on_gpu:
-            torch.cuda.synchronize()
-        timing["gpu_busy_s"] = timing.get("gpu_busy_s", 0.0) + sum(a.elapsed_time(b) for a, b in busy) * 1e-3
 
 
 class HostFrames:
@@ -302,19 +304,19 @@ class HostFrames:
         return [t.numpy() for t in self.items]
 
 
-def render_scene_file(renderer, path, out_path=None):
-    """≙ main() of the reference: picks one of the four loops from the scene's settings and writes
-    the PNG/APNG on rank 0.  Returns the list of RGBA8 frames on rank 0 (None elsewhere)."""
+def render_frames(renderer, path):
+    """The loop part of the reference's main(): picks one of the four loops from the scene's settings and returns
+    (RGBA8 frames on rank 0 / None elsewhere, scene info, per-frame fps or None for a still)."""
     rank, world = world_info()
     probe = capi.Scene(path, 0.0)
     info = probe.info
     cam = probe.desc.camera
     if cam.supersampling <= 1 and cam.lens_size != 0.0:
         raise RuntimeError("Depth of field needs supersampling.")
-    out_path = out_path or info.output_file.decode()
     h, w = probe.height, probe.width
     animated = info.frames > 1 and info.still_time == f32(capi.FLT_MAX)
     host = HostFrames(getattr(renderer, "device", torch.device("cpu")))
+    fps = None
 
     def to_host8(rgba):
         host.add(renderer.quantize(rgba.reshape(h, w, 4).contiguous()))
@@ -329,12 +331,15 @@ def render_scene_file(renderer, path, out_path=None):
         # every rank quantises its own frame (Color::scaleOut): RGBA8 travels, a quarter of the float picture
         render_units(renderer, path, units, lambda u, q: host.add(q.reshape(h, w, 4)),
                      payload=lambda pic: renderer.quantize(pic.reshape(h, w, 4).contiguous()))
+        if rank == 0:
+            # writeAPNGFrame(..., scene.fps()) with the frame's own scene (src/main.cpp:105): fps may be keyframed
+            fps = [capi.Scene(path, u[2]).info.fps for u in units]
     else:
         units = motion_blur_units(path, info)
-        state = {"acc": None, "frame": 0}
+        state = {"acc": None}
 
         def consume(u, pic):
-            frame, sub, _t, weight, k = u
+            _frame, sub, _t, weight, k = u
             if state["acc"] is None:
                 state["acc"] = torch.zeros_like(pic)
             renderer.mul_add(state["acc"], pic, weight)      # Picture::mulAdd, in sub-frame order
@@ -343,15 +348,20 @@ def render_scene_file(renderer, path, out_path=None):
                 state["acc"] = None
 
         render_units(renderer, path, units, consume)
+        if animated:
+            fps = [info.fps] * (units[-1][0] + 1)      # renderVideoMotionBlur uses origScene.fps() (src/main.cpp:152)
     frames8 = host.frames()
-    if rank != 0:
+    return (frames8 if rank == 0 else None), info, fps
+
+
+def render_scene_file(renderer, path, out_path=None):
+    """≙ main() of the reference: renders the file's still or animation and writes the PNG/APNG on rank 0.
+    Returns the list of RGBA8 frames on rank 0 (None elsewhere)."""
+    frames8, info, fps = render_frames(renderer, path)
+    if frames8 is None:
         return None
-    if animated:
-        if info.sub_frames <= 1:
-            # writeAPNGFrame(..., scene.fps()) with the frame's own scene (src/main.cpp:105): fps may be keyframed
-            fps = [capi.Scene(path, u[2]).info.fps for u in units]
-        else:
-            fps = [info.fps] * len(frames8)      # renderVideoMotionBlur uses origScene.fps() (src/main.cpp:152)
+    out_path = out_path or info.output_file.decode()
+    if fps is not None:
         capi.apng_write(out_path, frames8, fps)
     else:
         capi.png_write(out_path, frames8[0])
