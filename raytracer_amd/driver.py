@@ -240,6 +240,8 @@ def render_units(renderer, path, units, consume, payload=None):
     device = getattr(renderer, "device", torch.device("cpu"))
     payload = payload or (lambda pic: pic)
     bufs, gathered, pending = [None, None], [None, None], [None, None]
+    # RT_DRIVER_FORCE_GATHER=1 sends a one-rank group through the collective too (hardware test of the RCCL path)
+    collective = world > 1 or (dist.is_available() and dist.is_initialized() and os.environ.get("RT_DRIVER_FORCE_GATHER", "0") not in ("", "0"))
 
     def load(i):
         mine = i * world + rank
@@ -250,7 +252,7 @@ def render_units(renderer, path, units, consume, payload=None):
             pending[i % 2].wait()
             pending[i % 2] = None
         if rank == 0:
-            pics = gathered[i % 2] if world > 1 else [bufs[i % 2]]
+            pics = gathered[i % 2] if collective else [bufs[i % 2]]
             for r in range(world):
                 j = i * world + r
                 if j < len(units):
@@ -269,10 +271,12 @@ def render_units(renderer, path, units, consume, payload=None):
                 probe = capi.Scene(path, units[0][2])
                 out = payload(torch.zeros((probe.width * probe.height, 4), dtype=torch.float32, device=device))
             if i >= 2:
-                consume_round(i - 2)               # frees gathered[b]; round i is already on the GPU's queue
+                consume_round(i - 2)               # round i is already on the GPU's queue
             bufs[b] = out
-            if world > 1:
-                if rank == 0 and (gathered[b] is None or gathered[b][0].shape != out.shape or gathered[b][0].dtype != out.dtype):
+            if collective:
+                if rank == 0:
+                    # fresh tensors every round (the caching allocator makes that cheap): consumers may still be reading
+                    # the previous ones on another stream (HostFrames), which record_stream keeps alive, not unwritten
                     gathered[b] = [torch.empty_like(out) for _ in range(world)]
                 pending[b] = dist.gather(out, gathered[b] if rank == 0 else None, dst=0, async_op=True)
         for i in range(max(0, rounds - 2), rounds):

@@ -292,6 +292,30 @@ def test_rccl_all_reduce_on_the_library_owned_photon_textures(hip_ctx):
         dist.destroy_process_group()
 
 
+def test_rccl_gathers_of_the_pipelined_driver(monkeypatch):
+    """driver.render_units on a one-rank RCCL group with the collective forced on: async gathers (two buffers in
+    flight), the RGBA8 payload of plain animations and the float payload of motion blur all pass through RCCL and
+    the side-stream downloads; the frames must be those of the same loops without a process group."""
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import driver
+    r = driver.HipRenderer(0)
+    files = [scene_path("examples3/103_caustic_animation.xml"), scene_path("examples3/103_caustic_animation_mb8.xml")]
+    want = [driver.render_frames(r, f)[0] for f in files]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29644")
+    monkeypatch.setenv("RT_DRIVER_FORCE_GATHER", "1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for f, frames in zip(files, want):
+            got, _info, fps = driver.render_frames(r, f)
+            assert len(got) == len(frames) == 20 and len(fps) == 20
+            for a, b in zip(got, frames):
+                assert np.array_equal(a, b)
+    finally:
+        dist.destroy_process_group()
+
+
 # The reference built with its OWN Makefile flags (-Ofast -flto -march=native) is the secondary parity
 # target (SURVEY 8c): fast-math reorders its arithmetic, so the bar against it is the reference's own
 # flag noise — what its O-strict and O-fast builds differ by (tests/test_oracle_golden.py asserts those
