@@ -15,7 +15,7 @@
 //
 // Pinned build: g++ -O2 -std=c++17 -ffp-contract=off, baseline x86-64 (no FMA, no fast-math) = the
 // "O-strict" oracle of SURVEY §8c.  It is pinned against the real reference compiled the same way
-// (oracle/Makefile -> oracle/_ref/, oracle/ref_harness.cpp) by tests/test_oracle_vs_reference.py
+// (oracle/Makefile -> oracle/_ref/, oracle/ref_harness.cpp) by tests/test_oracle_golden.py (test_oracle_vs_live_reference*)
 // and the golden vectors under tests/golden/.
 //
 // Precision map: sub-expressions that the reference evaluates in double
