@@ -9,6 +9,9 @@ Needs oracle/_ref/ (built by `make -C oracle` from /root/reference/src, "O-stric
   <name>.fp.bin        flattened-scene word stream (ref_harness fingerprint) for the loader test
   <name>.kat.bin       Object::intersect / calcFresnel known answers (ref_harness kat)
   <name>.photon.bin    sparse photon textures after PhotonMapper::generate (ref_harness render)
+  x_dof_run{1,2}.png   two runs of the reference on examples2/7_dof.xml: its lens draws come from
+                       random_device-seeded engines (src/raytracer.cpp:44,86-89), so the two differ; their
+                       distance is the bar of the statistical depth-of-field test: `make_golden.py dof`
   ofast/<name>.png     the same scenes from the reference built with its own Makefile flags
                        (-Ofast -flto -march=native; host-dependent, the SECONDARY parity target of
                        SURVEY 8c): `make_golden.py ofast`
@@ -99,6 +102,11 @@ def main():
         out = os.path.join(HERE, name + ".png")
         timings[name + ".png"] = run([REF_EXE, os.path.join(SCENES, rel), out])
         print(name, "png done %.1fs" % timings[name + ".png"], flush=True)
+    if "dof" in only:
+        for i in (1, 2):
+            out = os.path.join(HERE, "x_dof_run%d.png" % i)
+            timings["x_dof_run%d.png" % i] = run([REF_EXE, os.path.join(SCENES, "examples2/7_dof.xml"), out])
+            print("dof run", i, "done %.1fs" % timings["x_dof_run%d.png" % i], flush=True)
     if "ofast" in only:
         os.makedirs(os.path.join(HERE, "ofast"), exist_ok=True)
         for name in OFAST_CONFIGS:

@@ -96,6 +96,15 @@ def fresnel(material, cos_rn, wavelength):
     return lib().oracle_fresnel(C.byref(material), cos_rn, wavelength)
 
 
+def dof_statistics(a8, b8):
+    """(PSNR over RGB in dB, |difference of the per-channel means| in LSB) of two RGBA8 pictures: the measure for
+    depth-of-field pictures, whose lens draws differ from run to run in the reference itself."""
+    a = a8[..., :3].astype(np.float64)
+    b = b8[..., :3].astype(np.float64)
+    psnr = 10.0 * np.log10(255.0 ** 2 / np.mean((a - b) ** 2))
+    return float(psnr), np.abs(a.reshape(-1, 3).mean(axis=0) - b.reshape(-1, 3).mean(axis=0))
+
+
 def image_diff(a8, b8):
     """Parity metric of BASELINE.json: fraction of pixels with any channel off by >1 LSB, max abs
     difference, PSNR (dB) over all channels."""

@@ -49,6 +49,26 @@ def test_oracle_rows_bit_exact(name):
             assert np.array_equal(img[y].view(np.uint32), data[k].view(np.uint32)), (name, t, int(y))
 
 
+def test_depth_of_field_statistics_against_two_reference_runs():
+    """examples2/7_dof.xml: the reference seeds its lens engines from random_device per worker (src/raytracer.cpp:44,
+    86-89), so its own two runs (tests/golden/x_dof_run{1,2}.png, make_golden.py dof) differ: that distance is the
+    bar.  The oracle's counter-hash draws must be as close to either run as the runs are to each other (PSNR within
+    0.5 dB) with per-channel means within 0.05 LSB."""
+    runs = [capi.png_read(golden_path("x_dof_run%d.png" % i), 0)[0] for i in (1, 2)]
+    ref_psnr, ref_means = oracle_lib.dof_statistics(runs[0], runs[1])
+    assert 40.0 < ref_psnr < 48.0 and ref_means.max() < 0.05, (ref_psnr, ref_means)
+    sc = capi.Scene(scene_path("examples2/7_dof.xml"), 0.0)
+    try:
+        for seed in (0, 5):
+            oracle_lib.set_dof_seed(seed)
+            q = capi.quantize(oracle_lib.render(sc, None, threads=8)[0])
+            for run in runs:
+                psnr, means = oracle_lib.dof_statistics(q, run)
+                assert psnr >= ref_psnr - 0.5 and means.max() < 0.05, (seed, psnr, ref_psnr, means)
+    finally:
+        oracle_lib.set_dof_seed(0)
+
+
 def test_oracle_photon_textures_bit_exact():
     w = np.fromfile(golden_path("c5_caustic_steps200.photon.bin"), dtype=np.uint32)
     size, n = int(w[0]), int(w[1])
