@@ -29,12 +29,17 @@ __global__ void kat_intersect_kernel(const DevScene sc, const unsigned* kind, co
 __global__ void kat_fresnel_kernel(const float* in, unsigned n, float* out);
 __global__ void mul_add_kernel(float* acc, const float* src, float factor, unsigned long long n);
 __global__ void quantize_kernel(const float4* rgba, uchar4* out, float gain, unsigned long long n);
-hipError_t build_triangle_bvh(const DevTriTest* tris, uint32_t first, uint32_t n, DevBvhNode* nodes);
+hipError_t build_triangle_bvh(const DevTriTest* tris, uint32_t first, uint32_t n, DevBvhPair* pairs);
 hipError_t photon_order_temp_bytes(unsigned capacity, unsigned key_bits, size_t* bytes);
 hipError_t photon_order_reduce(const unsigned long long* keys, const float4* vals, unsigned capacity, unsigned key_bits, unsigned texel_shift,
                                unsigned long long n_texels, float4* atlas, unsigned long long* sorted_keys, unsigned* sorted_index,
                                unsigned* long_runs, unsigned long long* words, void* temp, size_t temp_bytes, hipStream_t stream);
 constexpr int kFrameFieldsHost = 11;
+constexpr uint32_t kBvhLdsStackEntries = 24;   // 24 KB per workgroup of 256 lanes: with the 11 KB of frame tops, 4 blocks per CU still fit
+// dynamic LDS of trace_kernel / photon_kernel: [copy of the shade blob, if small][BVH stack columns, if the scene has a BVH]
+static size_t dynamic_lds_bytes(const rtd::DevScene& sc) {
+    return (sc.shade_blob_in_lds ? ((size_t(sc.shade_blob_bytes) + 15) & ~size_t(15)) : 0) + size_t(sc.bvh_lds_stack_entries) * 256 * sizeof(uint32_t);
+}
 constexpr size_t kMaxLdsBlobBytes = 28 * 1024;   // + 11 KB of frame tops: keeps 4 blocks per CU within the 160 KB LDS
 constexpr int kFrameRecordWordsHost = 12;       // trace_julia_kernel keeps every frame as a 48-byte record of its own
 constexpr int kJuliaBlockThreads = kJuliaWaves * 64, kJuliaShaderWavesHost = kJuliaWaves - kJuliaMarcherWaves;
@@ -277,7 +282,7 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     int rc;
     DevScene dev = ctx->dev;
     if (julia) dev.shade_blob_in_lds = 0;     // trace_julia_kernel's LDS belongs to its ray pool
-    const size_t lds = dev.shade_blob_in_lds ? dev.shade_blob_bytes : 0;
+    const size_t lds = julia ? 0 : dynamic_lds_bytes(dev);
     const uint64_t block_lanes = julia ? kJuliaPoolContexts : 256;   // ray trees in flight per workgroup
     {
         const int per_cu = julia ? std::min(1, ctx->julia_blocks_per_cu[stats]) : ctx->trace_blocks_per_cu[stats];
@@ -448,7 +453,7 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
         const bool stats = ctx->collect_stats;
         int blocks = 0;
         int rc;
-        const size_t lds = ctx->dev.shade_blob_in_lds ? ctx->dev.shade_blob_bytes : 0;
+        const size_t lds = dynamic_lds_bytes(ctx->dev);
         if (julia) rc = stats ? persistent_grid(ctx, photon_kernel<true, true>, job.n_roots, &blocks, lds) : persistent_grid(ctx, photon_kernel<true, false>, job.n_roots, &blocks, lds);
         else rc = stats ? persistent_grid(ctx, photon_kernel<false, true>, job.n_roots, &blocks, lds) : persistent_grid(ctx, photon_kernel<false, false>, job.n_roots, &blocks, lds);
         if (rc != RT_OK) return rc;
@@ -1034,6 +1039,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
     }
     sc.bvh_nodes = nullptr;
     sc.bvh_prims = nullptr;
+    sc.bvh_lds_stack_entries = 0;
     {
         // GPU-built BVH for every triangle run that is long enough (RT_OPT_BVH_MIN_TRIANGLES)
         // A run qualifies only if every triangle has a finite, non-zero area: a zero-area triangle makes
@@ -1054,22 +1060,23 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
         };
         size_t total_nodes = 0;
         for (const DevRun& r : runs) {
-            if (qualifies(r)) total_nodes += 2 * size_t(r.count) - 1;
+            if (qualifies(r)) total_nodes += size_t(r.count) - 1;
         }
         if (total_nodes > 0) {
-            if (ctx->bvh_nodes.bytes < total_nodes * sizeof(DevBvhNode)) RT_HIP_TRY(ctx, hipDeviceSynchronize());
-            if ((rc = grow(ctx, ctx->bvh_nodes, total_nodes * sizeof(DevBvhNode))) != RT_OK) return rc;
+            if (ctx->bvh_nodes.bytes < total_nodes * sizeof(DevBvhPair)) RT_HIP_TRY(ctx, hipDeviceSynchronize());
+            if ((rc = grow(ctx, ctx->bvh_nodes, total_nodes * sizeof(DevBvhPair))) != RT_OK) return rc;
             void* d_nodes = ctx->bvh_nodes.ptr;
             size_t at = 0;
             for (DevRun& r : runs) {
                 if (qualifies(r)) {
-                    RT_HIP_TRY(ctx, build_triangle_bvh(sc.tri_test, r.first_prim, r.count, static_cast<DevBvhNode*>(d_nodes) + at));
+                    RT_HIP_TRY(ctx, build_triangle_bvh(sc.tri_test, r.first_prim, r.count, static_cast<DevBvhPair*>(d_nodes) + at));
                     r.kind = RUN_TRIANGLE_BVH;
                     r.bvh_root = static_cast<uint32_t>(at);
-                    at += 2 * size_t(r.count) - 1;
+                    at += size_t(r.count) - 1;
                 }
             }
-            sc.bvh_nodes = static_cast<const DevBvhNode*>(d_nodes);
+            sc.bvh_nodes = static_cast<const DevBvhPair*>(d_nodes);
+            sc.bvh_lds_stack_entries = sc.shade_blob_in_lds ? 8 : kBvhLdsStackEntries;
             // the runs table was uploaded before the kinds changed: refresh it
             RT_HIP_TRY(ctx, hipMemcpy(const_cast<DevRun*>(sc.runs), runs.data(), runs.size() * sizeof(DevRun), hipMemcpyHostToDevice));
         }
@@ -1089,7 +1096,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
     {
         // persistent-grid sizes of the render kernels for this scene (the LDS copy of the shade blob decides), asked
         // once per upload so that a render call makes no runtime query (rt_render_device_noalloc makes none at all)
-        const size_t lds_t = sc.shade_blob_in_lds ? sc.shade_blob_bytes : 0;
+        const size_t lds_t = dynamic_lds_bytes(sc);
         RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->trace_blocks_per_cu[0], trace_kernel<false>, 256, lds_t));
         RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->trace_blocks_per_cu[1], trace_kernel<true>, 256, lds_t));
         if (sc.n_julias > 0) {

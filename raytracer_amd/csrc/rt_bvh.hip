@@ -3,9 +3,11 @@
 // ray (reference src/raytracer.cpp:126); the traversal in rt_kernels.hip returns the same winner as
 // that sequential scan (nearest hit, equal distances to the later scene object).
 //
-// Layout: a run of n >= 2 triangles gets 2n-1 nodes: internal nodes 0..n-2 (root 0), leaves
+// Construction layout: a run of n >= 2 triangles gets 2n-1 binary nodes: internal nodes 0..n-2 (root 0), leaves
 // n-1..2n-2 in Morton order.  Node = {lo[3], a, hi[3], b}: internal a/b = child node indices (relative
 // to the run's first node); leaf a = index into the triangle tables, b = kBvhLeaf.
+// Traversal layout (what build_triangle_bvh returns): the n-1 internal nodes as DevBvhPair records, each with the
+// boxes of BOTH children (bvh_pack_kernel); leaves are folded into their parent's child word.
 //
 // Leaf boxes are conservative for Triangle::intersect as written (src/objects.cpp:66-76): the test
 // accepts barycentrics down to -EPSILON, i.e. points up to EPSILON*(|e1|+|e2|) outside the triangle;
@@ -140,11 +142,29 @@ __global__ void bvh_fit_kernel(const unsigned long long* __restrict__ keys, cons
     }
 }
 
+__global__ void bvh_pack_kernel(const DevBvhNode* __restrict__ nodes, int n, DevBvhPair* __restrict__ pairs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const DevBvhNode a = nodes[nodes[i].left_or_first], b = nodes[nodes[i].count];
+    DevBvhPair p;
+    for (int c = 0; c < 3; c++) {
+        p.lo0[c] = a.lo[c];
+        p.hi0[c] = a.hi[c];
+        p.lo1[c] = b.lo[c];
+        p.hi1[c] = b.hi[c];
+    }
+    p.child0 = a.count == kBvhLeaf ? (kBvhLeafBit | a.left_or_first) : nodes[i].left_or_first;
+    p.child1 = b.count == kBvhLeaf ? (kBvhLeafBit | b.left_or_first) : nodes[i].count;
+    p.pad0 = p.pad1 = 0;
+    pairs[i] = p;
+}
+
 }  // namespace
 
-// Builds the BVH of triangles [first, first+n) of `tris` into nodes[0 .. 2n-2].  Synchronous.
-hipError_t build_triangle_bvh(const DevTriTest* tris, uint32_t first, uint32_t n, DevBvhNode* nodes) {
-    if (n < 2) return hipErrorInvalidValue;
+// Builds the BVH of triangles [first, first+n) of `tris` into pairs[0 .. n-2].  Synchronous.
+hipError_t build_triangle_bvh(const DevTriTest* tris, uint32_t first, uint32_t n, DevBvhPair* pairs) {
+    if (n < 2 || first + n >= kBvhLeafBit) return hipErrorInvalidValue;
+    DevBvhNode* nodes = nullptr;
     Box* boxes = nullptr;
     unsigned* bounds = nullptr;
     unsigned long long *keys = nullptr, *keys_sorted = nullptr;
@@ -153,10 +173,11 @@ hipError_t build_triangle_bvh(const DevTriTest* tris, uint32_t first, uint32_t n
     size_t temp_bytes = 0;
     hipError_t e = hipSuccess;
     auto done = [&](hipError_t err) {
-        (void)hipFree(boxes); (void)hipFree(bounds); (void)hipFree(keys); (void)hipFree(keys_sorted);
+        (void)hipFree(nodes); (void)hipFree(boxes); (void)hipFree(bounds); (void)hipFree(keys); (void)hipFree(keys_sorted);
         (void)hipFree(parent); (void)hipFree(arrivals); (void)hipFree(temp);
         return err;
     };
+    if ((e = hipMalloc(reinterpret_cast<void**>(&nodes), (2 * size_t(n) - 1) * sizeof(DevBvhNode))) != hipSuccess) return done(e);
     if ((e = hipMalloc(reinterpret_cast<void**>(&boxes), n * sizeof(Box))) != hipSuccess) return done(e);
     if ((e = hipMalloc(reinterpret_cast<void**>(&bounds), 6 * sizeof(unsigned))) != hipSuccess) return done(e);
     if ((e = hipMalloc(reinterpret_cast<void**>(&keys), n * sizeof(unsigned long long))) != hipSuccess) return done(e);
@@ -174,6 +195,7 @@ hipError_t build_triangle_bvh(const DevTriTest* tris, uint32_t first, uint32_t n
     if ((e = hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys, keys_sorted, static_cast<int>(n))) != hipSuccess) return done(e);
     hipLaunchKernelGGL(bvh_hierarchy_kernel, dim3(g), dim3(256), 0, nullptr, keys_sorted, static_cast<int>(n), nodes, parent);
     hipLaunchKernelGGL(bvh_fit_kernel, dim3(g), dim3(256), 0, nullptr, keys_sorted, boxes, first, static_cast<int>(n), nodes, parent, arrivals);
+    hipLaunchKernelGGL(bvh_pack_kernel, dim3(g), dim3(256), 0, nullptr, nodes, static_cast<int>(n), pairs);
     if ((e = hipGetLastError()) != hipSuccess) return done(e);
     e = hipDeviceSynchronize();
     return done(e);

@@ -92,12 +92,26 @@ struct DevTriChunk {
     float hi[3];
     float pad1;
 };
-// 32-byte BVH node: leaf when count > 0
+// Binary BVH node as the builder fits it (rt_bvh.hip): {lo, a, hi, b}; internal a/b = child node indices, leaf a = triangle, b = kBvhLeaf
 struct DevBvhNode {
     float lo[3];
-    uint32_t left_or_first;  // inner: index of left child (right = left+1); leaf: first entry in bvh_prims
+    uint32_t left_or_first;
     float hi[3];
     uint32_t count;
+};
+// What the traversal reads: one 64-byte record per INTERNAL node holding the boxes of both children, so that one
+// cache line decides which of them to enter (and which first).  child: bit 31 set = leaf, low bits = triangle index
+// into tri_test / tri_shade; else index of the child's record (relative to the run's first record).
+constexpr uint32_t kBvhLeafBit = 0x80000000u;
+struct DevBvhPair {
+    float lo0[3];
+    uint32_t child0;
+    float hi0[3];
+    uint32_t child1;
+    float lo1[3];
+    uint32_t pad0;
+    float hi1[3];
+    uint32_t pad1;
 };
 
 struct DevScene {
@@ -128,7 +142,7 @@ struct DevScene {
     const DevMaterial* materials;
     const DevTexture* textures;
     const uint32_t* texels;            // RGBA8 as in rt_scene_desc (R in the low byte)
-    const DevBvhNode* bvh_nodes;
+    const DevBvhPair* bvh_nodes;       // n-1 records per BVH run of n triangles (root = record 0 of the run)
     const uint32_t* bvh_prims;         // triangle indices (into tri_test) in leaf order
 
     // lights, materials, textures, tri_shade and the two per-object tables live in ONE allocation
@@ -137,6 +151,7 @@ struct DevScene {
     const unsigned char* shade_blob;
     uint32_t shade_blob_bytes;
     uint32_t shade_blob_in_lds;        // 0/1, decided by the host from the blob size
+    uint32_t bvh_lds_stack_entries;    // per-lane BVH stack entries kept in LDS (behind the blob copy); deeper ones go to scratch
 
     float4* photon_atlas;              // [n_slots][size][size]
     uint32_t photon_size;

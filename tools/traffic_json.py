@@ -26,7 +26,7 @@ def sections(path):
 def main():
     d, tag = sys.argv[1], sys.argv[2]
     res = {}
-    for w in ("c1", "c2", "c3", "c4", "c5"):
+    for w in ("c1", "c2", "c3", "c4", "c5", "mesh"):
         p = os.path.join(d, "%s_%s_pmc_summary.txt" % (tag, w))
         if not os.path.exists(p):
             continue
