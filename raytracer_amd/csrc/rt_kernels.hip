@@ -176,13 +176,17 @@ RT_DEV void finish_best_triangle(const ShadeTables& T, Lane& L) {
 // pushed only if the ray meets it too.  Stack entries are child words (leaf bit = a triangle to test).
 // (A "while-while" form, lanes holding a triangle waiting for the wave before the test, measured slower:
 // 6.1 ms against 4.6 ms on the 104k-triangle mesh; the walk is latency-bound and the mixed step overlaps more loads.)
+// 1/d per axis for the culling slab tests only (never for a value that reaches the picture): the hardware
+// reciprocal (1 ulp) instead of three IEEE divisions; rcp(+-0) = +-inf like the division.
+RT_DEV V3 cull_inverse(V3 d) { return {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)}; }
+
 struct SlabHit {
     bool overlap;
     float tnear;
 };
 RT_DEV SlabHit slab_test(float4 lo, float4 hi, V3 o, V3 inv, float qmax) {
     // fminf/fmaxf drop the NaNs of 0*inf so that an axis-parallel ray lying in a face plane is kept; the far side
-    // is widened by 2 ulp (robust traversal)
+    // is widened by 8 ulp (robust traversal with the 1-ulp reciprocal of cull_inverse)
     const float x0 = (lo.x - o.x) * inv.x, x1 = (hi.x - o.x) * inv.x;
     const float y0 = (lo.y - o.y) * inv.y, y1 = (hi.y - o.y) * inv.y;
     const float z0 = (lo.z - o.z) * inv.z, z1 = (hi.z - o.z) * inv.z;
@@ -195,7 +199,7 @@ RT_DEV SlabHit slab_test(float4 lo, float4 hi, V3 o, V3 inv, float qmax) {
     // more than that noise can be (1e-4 of the distance and of the box: ~10^3 ulp, no measurable cost).
     const float t_slack = 1e-4f * ((hi.x - lo.x) + (hi.y - lo.y) + (hi.z - lo.z));
     SlabHit h;
-    h.overlap = !(tnear > tfar * 1.0000004f) && !(tfar < -t_slack) && !(tnear * 0.9999f - t_slack > qmax);
+    h.overlap = !(tnear > tfar * 1.000001f) && !(tfar < -t_slack) && !(tnear * 0.9999f - t_slack > qmax);
     h.tnear = tnear;
     return h;
 }
@@ -211,7 +215,7 @@ struct BvhStackLds {
 template <bool STATS>
 RT_DEV void query_bvh(const DevScene& sc, Lane& L, unsigned act, unsigned bvh_root, unsigned first_object, unsigned first_prim, const BvhStackLds& fast, Counters& n) {
     if (act == 0u) return;
-    const V3 inv = {1.0f / L.qd.x, 1.0f / L.qd.y, 1.0f / L.qd.z};
+    const V3 inv = cull_inverse(L.qd);
     unsigned deep[64];
     unsigned sp = 0;
     unsigned cur = 0;
@@ -273,7 +277,7 @@ RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, const BvhS
     const auto chunks = to_constant(sc.tri_chunks);
     const auto sbounds = to_constant(sc.sphere_bounds);
     const float oo = dot(L.qo, L.qo);
-    const V3 inv = {1.0f / L.qd.x, 1.0f / L.qd.y, 1.0f / L.qd.z};
+    const V3 inv = cull_inverse(L.qd);
     for (unsigned r = 0; r < sc.n_runs; r++) {
         const int kind = runs[r].kind;
         const unsigned first_object = runs[r].first_object, first_prim = runs[r].first_prim, count = runs[r].count;
@@ -295,7 +299,7 @@ RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, const BvhS
                     const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
                     // (t_slack: see query_bvh — the triangle test's distance and the slab's are different roundings)
                     const float t_slack = cb->slack;
-                    const bool overlap = !(tnear > tfar * 1.0000004f) && !(tfar < -t_slack) && !(tnear * 0.9999f - t_slack > L.qmax);
+                    const bool overlap = !(tnear > tfar * 1.000001f) && !(tfar < -t_slack) && !(tnear * 0.9999f - t_slack > L.qmax);
                     if (!__any(act != 0u && overlap)) {
                         if (act != 0u) bump<STATS>(n, C_TRIANGLE_TESTS, count - i < RT_TRI_GROUP ? count - i : RT_TRI_GROUP);
                         continue;
