@@ -29,7 +29,7 @@ cli: raytracer_amd/rt_amd
 raytracer_amd/rt_amd: $(wildcard raytracer_amd/host/*.cpp) $(HOST_HDRS) raytracer_amd/librt_hip.so
 	$(CXX) $(HOSTFLAGS) -o $@ raytracer_amd/host/cli_main.cpp raytracer_amd/host/tracer_shim.cpp \
 	    raytracer_amd/host/scene_loader.cpp raytracer_amd/host/png_io.cpp \
-	    -Lraytracer_amd -lrt_hip -lz -Wl,-rpath,'$$ORIGIN'
+	    -Lraytracer_amd -lrt_hip -lz -rdynamic -Wl,-rpath,'$$ORIGIN'
 
 oracle:
 	$(MAKE) -C oracle

@@ -290,7 +290,7 @@ int rt_quantize_device(rt_ctx* ctx, const void* d_rgba, void* d_rgba8, float gai
                        void* hip_stream);
 
 /* ---- test hooks -------------------------------------------------------------------------------
- * One function of the path per call, for the known-answer parity tests (tests/test_gpu_parity.py: test_intersectors_against_reference_answers; vectors tests/golden/*.kat.bin).
+ * One function of the path per call, for the known-answer parity tests (tests/test_gpu_parity.py: test_intersectors_against_reference_answers; vectors tests/golden/<name>.kat.bin).
  * rt_kat_intersect ≙ Object::intersect (reference src/objects.h:124-126): n rays of 7 floats
  * (origin, direction as given to the Ray constructor, max_distance) against scene object
  * object_index[i]; out = 12 floats per ray (hit flag, distance, point, normal, uv, photon uv).

@@ -838,6 +838,13 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
             const bool mine = L.state == S_RESOLVE;
             bool done = false;
             Col value = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (STATS) {
+                const int n_trace = __popcll(__ballot(mine && !fresh && L.qkind == Q_TRACE)), n_shadow = __popcll(__ballot(mine && !fresh && L.qkind == Q_SHADOW));
+                if ((threadIdx.x & 63) == 0 && n_trace > 0 && n_shadow > 0) {
+                    n.v[D_RESOLVE_MIXED]++;
+                    n.v[D_RESOLVE_MINORITY_LANES] += static_cast<unsigned long long>(n_trace < n_shadow ? n_trace : n_shadow);
+                }
+            }
             if (mine && !fresh) resolve_lane<STATS>(sc, T, job, frames, L, n, done, value);
             t_fetch_outer = STATS ? clock64() : 0;
             if (mine && done) store_sample(sc, job, L, value);

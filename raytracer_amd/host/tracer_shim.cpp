@@ -69,6 +69,33 @@ Picture8 GpuSession::render8() {
     return p;
 }
 
+Picture8 GpuSession::render8(const rt_bands& bands) {
+    Picture8 p;
+    p.width = width_;
+    const uint64_t n = rt_bands_pixel_count(width_, height_, &bands);
+    p.height = width_ ? static_cast<uint32_t>(n / width_) : 0;
+    p.pixels.resize(size_t(n) * 4);
+    if (n == 0) return p;
+    CallLap lap(g_calls.render);
+    check(rt_render_rgba8(ctx_, &bands, p.pixels.data(), 1.0f, nullptr), "raytrace");
+    return p;
+}
+
+Picture8 scale_out(const Picture& picture) {
+    Picture8 p;
+    p.width = picture.width();
+    p.height = picture.height();
+    const size_t n = size_t(p.width) * p.height * 4;
+    p.pixels.resize(n);
+    const float* v = picture.data();
+    for (size_t i = 0; i < n; i++) {
+        const float c = v[i] < 0.0f ? 0.0f : (v[i] > 1.0f ? 1.0f : v[i]);
+        const float s = c * 255.0f;
+        p.pixels[i] = static_cast<uint8_t>(s != s ? 0.0f : s);   // truncation; NaN -> 0
+    }
+    return p;
+}
+
 void GpuSession::accumulate(float weight, bool first) {
     CallLap lap(g_calls.render);
     check(rt_render_accumulate(ctx_, nullptr, weight, first ? 1 : 0), "raytrace");

@@ -44,6 +44,9 @@ struct Picture8 {
     std::vector<uint8_t> pixels;
 };
 
+// Color::scaleOut of a whole picture on the host (reference src/types.h:274-282, gain 1): u8(clamp(v, 0, 1) * 255.0f)
+Picture8 scale_out(const Picture& picture);
+
 // One GPU.  The reference's Scene carries its photon textures inside its objects; here they live on
 // the device inside the session, so a Scene handed to PhotonMapper::generate must be rendered
 // through the same session (the default session is process-wide, like the reference's free calls).
@@ -58,6 +61,10 @@ public:
     void photons();                            // rt_photon_generate
     Picture render();                          // rt_render
     Picture8 render8();                        // rt_render_rgba8
+    // rows of the bands only, compact (rt_bands: band b covers image rows [b*band_rows, (b+1)*band_rows))
+    Picture8 render8(const rt_bands& bands);
+    uint32_t width() const { return width_; }
+    uint32_t height() const { return height_; }
     void accumulate(float weight, bool first); // rt_render_accumulate
     Picture8 accumulated8();                   // rt_accumulated_rgba8
     static GpuSession& process_default();

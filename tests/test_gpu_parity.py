@@ -794,6 +794,33 @@ def test_cli_writes_the_file_the_reference_executable_writes(tmp_path, seed):
     assert open(a, "rb").read() == open(b, "rb").read()
 
 
+RT_AMD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer_amd", "rt_amd")
+
+
+@pytest.mark.parametrize("kind,tags,devices", [
+    ("still", "", 2), ("still", "", 3),
+    ("still_blur", '<motionblur subframes="5"/>', 2),
+    ("animation", '<animation length="0.7" fps="10;20"/>', 3),
+    ("animation_blur", '<animation length="0.5" fps="8"/><motionblur subframes="2;4"/>', 2),
+])
+def test_cli_on_several_devices_writes_the_same_file(tmp_path, kind, tags, devices):
+    """rt_amd --devices N (one host thread and one rt_ctx per GPU, C++ only): bands of a still, sub-frames of a blurred
+    still, frames of an animation (with and without blur, keyframed fps and sub-frame count) come back in order and
+    the file is byte for byte the single-device one.  This box has one GPU: RT_AMD_DEVICE_LIST names it N times, which
+    exercises the sharding, the ordering and the per-context state; N distinct GPUs differ only in the device index
+    handed to rt_create."""
+    import subprocess
+    from test_driver_distributed import small_scene
+    scene = small_scene(tmp_path, tags, size=(64, 44), steps=40)
+    one, many = str(tmp_path / "one.png"), str(tmp_path / "many.png")
+    subprocess.check_call([RT_AMD, scene, one], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, RT_AMD_DEVICE_LIST=",".join(["0"] * devices))
+    subprocess.check_call([RT_AMD, "--devices", str(devices), scene, many], stdout=subprocess.DEVNULL, env=env)
+    assert open(one, "rb").read() == open(many, "rb").read()
+    _img, n = capi.png_read(one, 0)
+    assert n == {"still": 1, "still_blur": 1, "animation": 7, "animation_blur": 4}[kind]
+
+
 ALL_SCENES = [
     ("examples/example2.xml", 0.0), ("examples/example3.xml", 0.0), ("examples/example4.xml", 0.0),
     ("examples/example5.xml", 0.0), ("examples/example6.xml", 0.0), ("examples/example7.xml", 0.0),

@@ -54,7 +54,8 @@ def main():
                      "resolve_phases", "resolve_lanes", "de_wave_iter_slots", "query_cycles", "march_cycles",
                      "normal_cycles", "resolve_cycles", "tri_cycles", "sphere_cycles",
                      "r_node", "r_light", "r_shadowsetup", "r_fresnel", "r_return", "r_fetch",
-                     "m_tail_cycles", "m_idle_cycles", "m_refill_cycles", "t_wait_cycles", "m_tail_blocks", "m_tail_lanes"]
+                     "m_tail_cycles", "m_idle_cycles", "m_refill_cycles", "t_wait_cycles", "m_tail_blocks", "m_tail_lanes",
+                     "resolve_mixed", "resolve_minority_lanes"]
             dbg = dict(zip(names, list(words)[16:nw]))
             print("  scheduler", dbg, flush=True)
             for ph in ("query", "march", "normal", "resolve"):
