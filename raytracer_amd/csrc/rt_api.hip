@@ -35,12 +35,12 @@ hipError_t photon_order_reduce(const unsigned long long* keys, const float4* val
                                unsigned long long n_texels, float4* atlas, unsigned long long* sorted_keys, unsigned* sorted_index,
                                unsigned* long_runs, unsigned long long* words, void* temp, size_t temp_bytes, hipStream_t stream);
 constexpr int kFrameFieldsHost = 11;
-constexpr uint32_t kBvhLdsStackEntries = 24;   // 24 KB per workgroup of 256 lanes: with the 11 KB of frame tops, 4 blocks per CU still fit
+constexpr uint32_t kBvhLdsStackEntries = 16;   // 16 KB per workgroup of 256 lanes: with the 36 KB of frame tops and parked node state, 3 blocks per CU still fit
 // dynamic LDS of trace_kernel / photon_kernel: [copy of the shade blob, if small][BVH stack columns, if the scene has a BVH]
 static size_t dynamic_lds_bytes(const rtd::DevScene& sc) {
     return (sc.shade_blob_in_lds ? ((size_t(sc.shade_blob_bytes) + 15) & ~size_t(15)) : 0) + size_t(sc.bvh_lds_stack_entries) * 256 * sizeof(uint32_t);
 }
-constexpr size_t kMaxLdsBlobBytes = 28 * 1024;   // + 11 KB of frame tops: keeps 4 blocks per CU within the 160 KB LDS
+constexpr size_t kMaxLdsBlobBytes = 16 * 1024;   // + 11 KB of frame tops + 25 KB of parked node state: 3 blocks per CU within the 160 KB LDS
 constexpr int kFrameRecordWordsHost = 12;       // trace_julia_kernel keeps every frame as a 48-byte record of its own
 constexpr int kJuliaBlockThreads = kJuliaWaves * 64, kJuliaShaderWavesHost = kJuliaWaves - kJuliaMarcherWaves;
 }  // namespace rtd

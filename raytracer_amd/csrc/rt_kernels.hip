@@ -779,6 +779,43 @@ RT_DEV void flush_counters(const Counters& n, unsigned long long* out) {
     }
 }
 
+// What a lane knows about the node it is shading and about its sample is not touched while its query runs.  Kept
+// in registers it is what the compiler spills around the object loop (71 VGPRs of scratch at the 168-register
+// budget: ~6 GB of HBM writes per C3 frame, since the scratch of 3072 waves does not stay in L2); trace_kernel
+// parks it in LDS at the end of every resolve phase and takes it back at the start of the next one, for all lanes
+// alike (uniform control flow), so that the registers are dead in between.
+constexpr int kParkWords = 25;
+RT_DEV void park_node(float* col, const Lane& L) {
+    const float w[kParkWords] = {L.n_point.x, L.n_point.y, L.n_point.z, L.n_normal.x, L.n_normal.y, L.n_normal.z, L.n_dir.x, L.n_dir.y, L.n_dir.z,
+                                 L.n_ph.x, L.n_ph.y, L.n_cos, __uint_as_float(L.n_obj), L.acc[0], L.acc[1], L.acc[2], L.matcol[0], L.matcol[1], L.matcol[2],
+                                 __uint_as_float(L.li), __uint_as_float(L.sp), L.wavelength, __int_as_float(L.hue),
+                                 __uint_as_float(static_cast<unsigned>(L.out_slot)), __uint_as_float(static_cast<unsigned>(L.out_slot >> 32))};
+#pragma unroll
+    for (int i = 0; i < kParkWords; i++) col[i * 256] = w[i];
+}
+RT_DEV void unpark_node(const float* col, Lane& L) {
+    float w[kParkWords];
+#pragma unroll
+    for (int i = 0; i < kParkWords; i++) w[i] = col[i * 256];
+    L.n_point = v3(w[0], w[1], w[2]);
+    L.n_normal = v3(w[3], w[4], w[5]);
+    L.n_dir = v3(w[6], w[7], w[8]);
+    L.n_ph = {w[9], w[10]};
+    L.n_cos = w[11];
+    L.n_obj = __float_as_uint(w[12]);
+    L.acc[0] = w[13];
+    L.acc[1] = w[14];
+    L.acc[2] = w[15];
+    L.matcol[0] = w[16];
+    L.matcol[1] = w[17];
+    L.matcol[2] = w[18];
+    L.li = __float_as_uint(w[19]);
+    L.sp = __float_as_uint(w[20]);
+    L.wavelength = w[21];
+    L.hue = __float_as_int(w[22]);
+    L.out_slot = static_cast<unsigned long long>(__float_as_uint(w[23])) | (static_cast<unsigned long long>(__float_as_uint(w[24])) << 32);
+}
+
 // ---- the render kernel (scenes without Julia sets) ----------------------------------------------------
 template <bool STATS>
 __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(const DevScene sc_global, const DevJob job) {
@@ -806,12 +843,23 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
 
     Lane L;
     __shared__ float top_store[kFrameFields * 256];
+    __shared__ float park_store[kParkWords * 256];
+    float* const park = park_store + threadIdx.x;
     const TopInLds frames = {top_store + threadIdx.x, 256u, stack};
     L.state = S_RESOLVE;       // "resolve" of a lane without a sample = fetch one
     L.qkind = -1;
     L.sp = 0;
     L.jidx = 0;
     L.jstep = 0;
+    L.n_point = L.n_normal = L.n_dir = v3(0.0f, 0.0f, 0.0f);
+    L.n_ph = {0.0f, 0.0f};
+    L.n_cos = 0.0f;
+    L.n_obj = L.li = 0u;
+    L.acc[0] = L.acc[1] = L.acc[2] = L.matcol[0] = L.matcol[1] = L.matcol[2] = 0.0f;
+    L.wavelength = 0.0f;
+    L.hue = -1;
+    L.out_slot = 0ull;
+    park_node(park, L);
     bool fresh = true;         // lane holds no sample yet
     bool want = false;         // lane is idle and waits for the next refill
     WaveIds wave_ids = wave_ids_begin(gid, job.n_waves, job.static_blocks);
@@ -838,6 +886,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
             const bool mine = L.state == S_RESOLVE;
             bool done = false;
             Col value = {0.0f, 0.0f, 0.0f, 0.0f};
+            unpark_node(park, L);
             if (STATS) {
                 const int n_trace = __popcll(__ballot(mine && !fresh && L.qkind == Q_TRACE)), n_shadow = __popcll(__ballot(mine && !fresh && L.qkind == Q_SHADOW));
                 if ((threadIdx.x & 63) == 0 && n_trace > 0 && n_shadow > 0) {
@@ -869,6 +918,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
                     }
                 }
             }
+            park_node(park, L);
         }
         if (STATS && phase == S_RESOLVE && (threadIdx.x & 63) == 0) n.v[D_R_FETCH_CYCLES] += static_cast<unsigned long long>(clock64() - t_fetch_outer);
         if (STATS && (threadIdx.x & 63) == 0) {
