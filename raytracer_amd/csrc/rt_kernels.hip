@@ -119,7 +119,11 @@ RT_DEV void bump(Counters& n, int slot, unsigned long long by = 1) {
 
 // A candidate hit of scene object `obj` reaches the per-query acceptance rule
 // (src/raytracer.cpp:128-141 for Q_TRACE, :222-226 for Q_SHADOW, src/photonmap.cpp:68-74 for Q_PHOTON).
-RT_DEV void accept_hit(Lane& L, const HitRec& h, unsigned obj, float transmittance, float refr_norm) {
+// `hit_col` (trace_kernel): the lane's parking column in LDS.  The record of an accepted hit goes there instead of
+// into registers that would stay live over the whole object loop: words 0-2 point, 3-5 normal, 6-7 uv, 9-10 photon uv
+// — the slots of n_point, n_normal, n_dir.xy and n_ph (park_node), which are dead while a Q_TRACE query is in flight
+// (a shadow query never gets here) and are exactly where the resolve phase wants the winner's record.
+RT_DEV void accept_hit(Lane& L, const HitRec& h, unsigned obj, float transmittance, float refr_norm, float* hit_col = nullptr) {
     if (L.qkind == Q_SHADOW) {
         if (dot(L.qd, h.normal) < 0.0f) {   // only front faces cast shadows
             L.blocked = 1u;
@@ -133,7 +137,21 @@ RT_DEV void accept_hit(Lane& L, const HitRec& h, unsigned obj, float transmittan
         if (cosv >= 0.0f && (transmittance == 0.0f || refr_norm == 0.0f)) return;   // unseen back face
     }
     L.found = 1u;
-    L.best = h;
+    if (hit_col != nullptr) {
+        hit_col[0 * 256] = h.point.x;
+        hit_col[1 * 256] = h.point.y;
+        hit_col[2 * 256] = h.point.z;
+        hit_col[3 * 256] = h.normal.x;
+        hit_col[4 * 256] = h.normal.y;
+        hit_col[5 * 256] = h.normal.z;
+        hit_col[6 * 256] = h.uv.x;
+        hit_col[7 * 256] = h.uv.y;
+        hit_col[9 * 256] = h.ph.x;
+        hit_col[10 * 256] = h.ph.y;
+        L.best.dist = h.dist;
+    } else {
+        L.best = h;
+    }
     L.best_obj = obj;
     L.best_cos = cosv;
     L.best_tri = kNoTriangle;
@@ -266,7 +284,7 @@ RT_DEV void query_bvh(const DevScene& sc, Lane& L, unsigned act, unsigned bvh_ro
 // object in scene order.  `runs`, the geometry tables and the material flags are read at uniform
 // addresses.
 template <bool STATS>
-RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, const BvhStackLds& bvh_stack, Counters& n) {
+RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, const BvhStackLds& bvh_stack, Counters& n, float* hit_col = nullptr) {
     unsigned act = in_phase ? L.qactive : 0u;   // 32-bit lane value on purpose (see Lane)
     const auto runs = to_constant(sc.runs);
     const auto tris = to_constant(sc.tri_test);
@@ -365,7 +383,7 @@ RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, const BvhS
                     HitRec h;
                     if (sphere_intersect(spheres + first_prim + i, L.qo, L.qd, L.qmax, h)) {
                         const unsigned m = obj_mat[first_object + i];
-                        accept_hit(L, h, first_object + i, mats[m].transmittance, mats[m].refr_norm);
+                        accept_hit(L, h, first_object + i, mats[m].transmittance, mats[m].refr_norm, hit_col);
                         act = L.qactive;
                     }
                 }
@@ -880,13 +898,19 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
         }
         if (phase == S_QUERY) {
             const bool mine = L.state == S_QUERY;
-            query_objects<STATS>(sc, L, mine, bvh_stack, n);
+            query_objects<STATS>(sc, L, mine, bvh_stack, n, park);
             if (mine) L.state = S_RESOLVE;
         } else {   // S_RESOLVE
             const bool mine = L.state == S_RESOLVE;
             bool done = false;
             Col value = {0.0f, 0.0f, 0.0f, 0.0f};
             unpark_node(park, L);
+            // a sphere winner's record was written into the parking slots (accept_hit); a triangle winner's is built by
+            // finish_best_triangle.  Unconditional on purpose: the registers must not carry a value across the query.
+            L.best.point = L.n_point;
+            L.best.normal = L.n_normal;
+            L.best.uv = {L.n_dir.x, L.n_dir.y};
+            L.best.ph = L.n_ph;
             if (STATS) {
                 const int n_trace = __popcll(__ballot(mine && !fresh && L.qkind == Q_TRACE)), n_shadow = __popcll(__ballot(mine && !fresh && L.qkind == Q_SHADOW));
                 if ((threadIdx.x & 63) == 0 && n_trace > 0 && n_shadow > 0) {
