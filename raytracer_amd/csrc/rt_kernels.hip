@@ -119,11 +119,21 @@ RT_DEV void bump(Counters& n, int slot, unsigned long long by = 1) {
 
 // A candidate hit of scene object `obj` reaches the per-query acceptance rule
 // (src/raytracer.cpp:128-141 for Q_TRACE, :222-226 for Q_SHADOW, src/photonmap.cpp:68-74 for Q_PHOTON).
-// `hit_col` (trace_kernel): the lane's parking column in LDS.  The record of an accepted hit goes there instead of
-// into registers that would stay live over the whole object loop: words 0-2 point, 3-5 normal, 6-7 uv, 9-10 photon uv
-// — the slots of n_point, n_normal, n_dir.xy and n_ph (park_node), which are dead while a Q_TRACE query is in flight
-// (a shadow query never gets here) and are exactly where the resolve phase wants the winner's record.
-RT_DEV void accept_hit(Lane& L, const HitRec& h, unsigned obj, float transmittance, float refr_norm, float* hit_col = nullptr) {
+// Where the record of an accepted hit goes.  Kept in the lane's registers it stays live over the whole object loop;
+// both render kernels have an LDS home for it instead (word offsets and stride in floats):
+//   trace_kernel        the lane's parking column: the slots of n_point, n_normal, n_dir.xy and n_ph (park_node), which
+//                       are dead while a Q_TRACE query is in flight (a shadow query never records a hit) and are
+//                       exactly where the resolve phase wants the winner's record;
+//   trace_julia_kernel  the union words of the ray's context record, where ctx_store would put it anyway.
+// base == nullptr keeps the record in L.best (photon pass, Julia hits judged by the shader wave itself).
+struct HitSink {
+    float* base;
+    unsigned stride;
+    unsigned char point, normal, uv, phx, phy;
+};
+constexpr HitSink kHitInRegisters = {nullptr, 0u, 0, 0, 0, 0, 0};
+
+RT_DEV void accept_hit(Lane& L, const HitRec& h, unsigned obj, float transmittance, float refr_norm, const HitSink& sink = kHitInRegisters) {
     if (L.qkind == Q_SHADOW) {
         if (dot(L.qd, h.normal) < 0.0f) {   // only front faces cast shadows
             L.blocked = 1u;
@@ -137,17 +147,19 @@ RT_DEV void accept_hit(Lane& L, const HitRec& h, unsigned obj, float transmittan
         if (cosv >= 0.0f && (transmittance == 0.0f || refr_norm == 0.0f)) return;   // unseen back face
     }
     L.found = 1u;
-    if (hit_col != nullptr) {
-        hit_col[0 * 256] = h.point.x;
-        hit_col[1 * 256] = h.point.y;
-        hit_col[2 * 256] = h.point.z;
-        hit_col[3 * 256] = h.normal.x;
-        hit_col[4 * 256] = h.normal.y;
-        hit_col[5 * 256] = h.normal.z;
-        hit_col[6 * 256] = h.uv.x;
-        hit_col[7 * 256] = h.uv.y;
-        hit_col[9 * 256] = h.ph.x;
-        hit_col[10 * 256] = h.ph.y;
+    if (sink.base != nullptr) {
+        float* const b = sink.base;
+        const unsigned st = sink.stride;
+        b[(sink.point + 0u) * st] = h.point.x;
+        b[(sink.point + 1u) * st] = h.point.y;
+        b[(sink.point + 2u) * st] = h.point.z;
+        b[(sink.normal + 0u) * st] = h.normal.x;
+        b[(sink.normal + 1u) * st] = h.normal.y;
+        b[(sink.normal + 2u) * st] = h.normal.z;
+        b[(sink.uv + 0u) * st] = h.uv.x;
+        b[(sink.uv + 1u) * st] = h.uv.y;
+        b[sink.phx * st] = h.ph.x;
+        b[sink.phy * st] = h.ph.y;
         L.best.dist = h.dist;
     } else {
         L.best = h;
@@ -284,7 +296,7 @@ RT_DEV void query_bvh(const DevScene& sc, Lane& L, unsigned act, unsigned bvh_ro
 // object in scene order.  `runs`, the geometry tables and the material flags are read at uniform
 // addresses.
 template <bool STATS>
-RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, const BvhStackLds& bvh_stack, Counters& n, float* hit_col = nullptr) {
+RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, const BvhStackLds& bvh_stack, Counters& n, const HitSink& sink = kHitInRegisters) {
     unsigned act = in_phase ? L.qactive : 0u;   // 32-bit lane value on purpose (see Lane)
     const auto runs = to_constant(sc.runs);
     const auto tris = to_constant(sc.tri_test);
@@ -383,7 +395,7 @@ RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, const BvhS
                     HitRec h;
                     if (sphere_intersect(spheres + first_prim + i, L.qo, L.qd, L.qmax, h)) {
                         const unsigned m = obj_mat[first_object + i];
-                        accept_hit(L, h, first_object + i, mats[m].transmittance, mats[m].refr_norm, hit_col);
+                        accept_hit(L, h, first_object + i, mats[m].transmittance, mats[m].refr_norm, sink);
                         act = L.qactive;
                     }
                 }
@@ -898,14 +910,15 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
         }
         if (phase == S_QUERY) {
             const bool mine = L.state == S_QUERY;
-            query_objects<STATS>(sc, L, mine, bvh_stack, n, park);
+            const HitSink sink = {park, 256u, 0, 3, 6, 9, 10};
+            query_objects<STATS>(sc, L, mine, bvh_stack, n, sink);
             if (mine) L.state = S_RESOLVE;
         } else {   // S_RESOLVE
             const bool mine = L.state == S_RESOLVE;
             bool done = false;
             Col value = {0.0f, 0.0f, 0.0f, 0.0f};
             unpark_node(park, L);
-            // a sphere winner's record was written into the parking slots (accept_hit); a triangle winner's is built by
+            // a sphere winner's record was written into the parking slots (accept_hit, HitSink); a triangle winner's is built by
             // finish_best_triangle.  Unconditional on purpose: the registers must not carry a value across the query.
             L.best.point = L.n_point;
             L.best.normal = L.n_normal;
@@ -1157,8 +1170,31 @@ RT_DEV void ctx_load(const DevScene& sc, const float* c, Lane& L, bool& fresh, u
     }
     (void)sc;
 }
-// Lane -> context, for a lane whose new query is under way (waiting: a Julia job goes with it).
-RT_DEV void ctx_store(float* c, const Lane& L, bool waiting) {
+// Lane -> context in two parts, so that what the object loop does not touch is out of the registers while it runs.
+// ctx_store_cold (before the loop): the sample's words, the shaded node of a shadow query, and the best record of a
+// trace query that does not run the loop in this batch (`keeps_best`: it moves on to the next Julia set).
+RT_DEV void ctx_store_cold(float* c, const Lane& L, bool keeps_best) {
+    const unsigned misc = static_cast<unsigned>(L.hue + 1) | (L.sp << 8) | (L.li << 16);
+    c[CW_SLOT_LO] = __uint_as_float(static_cast<unsigned>(L.out_slot));
+    c[CW_SLOT_HI] = __uint_as_float(static_cast<unsigned>(L.out_slot >> 32));
+    c[CW_MISC] = __uint_as_float(misc);
+    if (L.qkind == Q_SHADOW) {
+        ctx_put(c, CW_UNION, F4{L.n_point.x, L.n_point.y, L.n_point.z, L.n_cos});
+        ctx_put(c, CW_UNION + 4, F4{L.n_normal.x, L.n_normal.y, L.n_normal.z, __uint_as_float(L.n_obj)});
+        ctx_put(c, CW_UNION + 8, F4{L.n_dir.x, L.n_dir.y, L.n_dir.z, L.n_ph.x});
+        ctx_put(c, CW_UNION + 12, F4{L.matcol[0], L.matcol[1], L.matcol[2], L.n_ph.y});
+        ctx_put(c, CW_UNION + 16, F4{L.acc[0], L.acc[1], L.acc[2], 0.0f});
+    } else if (keeps_best) {
+        c[CW_UNION + 6] = L.best.uv.x;
+        c[CW_UNION + 7] = L.best.uv.y;
+        ctx_put(c, CW_UNION + 8, F4{L.best.point.x, L.best.point.y, L.best.point.z, L.best.ph.x});
+        ctx_put(c, CW_UNION + 12, F4{L.best.normal.x, L.best.normal.y, L.best.normal.z, L.best.ph.y});
+    }
+}
+// The HitSink of a context: accept_hit writes the record of a trace query's winner straight into the union words.
+RT_DEV HitSink ctx_hit_sink(float* c) { return {c, 1u, CW_UNION + 8, CW_UNION + 12, CW_UNION + 6, CW_UNION + 11, CW_UNION + 15}; }
+// ctx_store_hot (after the loop): the query and its state (waiting: a Julia job goes with it).
+RT_DEV void ctx_store_hot(float* c, const Lane& L, bool waiting) {
     unsigned flags = static_cast<unsigned>(L.qkind) & CF_KIND_MASK;
     if (L.qactive) flags |= CF_QACTIVE;
     if (L.blocked) flags |= CF_BLOCKED;
@@ -1170,20 +1206,11 @@ RT_DEV void ctx_store(float* c, const Lane& L, bool waiting) {
         ctx_put(c, CW_JP, F4{L.jp.x, L.jp.y, L.jp.z, 0.0f});
         ctx_put(c, CW_JD, F4{L.jd.x, L.jd.y, L.jd.z, __uint_as_float(JOB_PENDING)});
     }
-    const unsigned misc = static_cast<unsigned>(L.hue + 1) | (L.sp << 8) | (L.li << 16);
-    ctx_put(c, CW_SLOT_LO, F4{__uint_as_float(static_cast<unsigned>(L.out_slot)), __uint_as_float(static_cast<unsigned>(L.out_slot >> 32)),
-                              __uint_as_float(misc), __uint_as_float(L.jidx)});
-    if (L.qkind == Q_SHADOW) {
-        ctx_put(c, CW_UNION, F4{L.n_point.x, L.n_point.y, L.n_point.z, L.n_cos});
-        ctx_put(c, CW_UNION + 4, F4{L.n_normal.x, L.n_normal.y, L.n_normal.z, __uint_as_float(L.n_obj)});
-        ctx_put(c, CW_UNION + 8, F4{L.n_dir.x, L.n_dir.y, L.n_dir.z, L.n_ph.x});
-        ctx_put(c, CW_UNION + 12, F4{L.matcol[0], L.matcol[1], L.matcol[2], L.n_ph.y});
-        ctx_put(c, CW_UNION + 16, F4{L.acc[0], L.acc[1], L.acc[2], 0.0f});
-    } else {
+    c[CW_JIDX] = __uint_as_float(L.jidx);
+    if (L.qkind != Q_SHADOW) {
         ctx_put(c, CW_UNION, F4{L.best.dist, __uint_as_float(L.best_obj), L.best_cos, __uint_as_float(L.best_tri)});
-        ctx_put(c, CW_UNION + 4, F4{L.best_u, L.best_v, L.best.uv.x, L.best.uv.y});
-        ctx_put(c, CW_UNION + 8, F4{L.best.point.x, L.best.point.y, L.best.point.z, L.best.ph.x});
-        ctx_put(c, CW_UNION + 12, F4{L.best.normal.x, L.best.normal.y, L.best.normal.z, L.best.ph.y});
+        c[CW_UNION + 4] = L.best_u;
+        c[CW_UNION + 5] = L.best_v;
     }
 }
 
@@ -1451,6 +1478,9 @@ RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob&
             }
         }
         charge(D_RESOLVE_CYCLES);
+        const bool alive = mine && !died;
+        float* const my_ctx = sh.ctx[mine ? id : 0u];
+        if (alive) ctx_store_cold(my_ctx, L, L.state != S_QUERY);
         // ---- the new query against everything that is not a Julia set, then the first set it enters
         if (__any(L.state == S_QUERY)) {
             const bool q = L.state == S_QUERY;
@@ -1459,7 +1489,7 @@ RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob&
                 if (q) n.v[D_QUERY_LANES]++;
             }
             const BvhStackLds no_lds_stack = {nullptr, 0u, 0u};
-            query_objects<STATS>(sc, L, q, no_lds_stack, n);
+            query_objects<STATS>(sc, L, q, no_lds_stack, n, ctx_hit_sink(my_ctx));
             if (q) {
                 L.state = S_RESOLVE;
                 if (L.qactive) {
@@ -1476,8 +1506,7 @@ RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob&
             }
         }
         // ---- back into the pool, and on to the next ring
-        const bool alive = mine && !died;
-        if (alive) ctx_store(sh.ctx[id], L, push_job);
+        if (alive) ctx_store_hot(my_ctx, L, push_job);
         ring_push(sh.ring[R_MARCH], &sh.ctl[2 * R_MARCH + 1], alive && push_job, id);
         ring_push(sh.ring[R_READY_T], &sh.ctl[2 * R_READY_T + 1], alive && !push_job && L.qkind != Q_SHADOW, id);
         ring_push(sh.ring[R_READY_S], &sh.ctl[2 * R_READY_S + 1], alive && !push_job && L.qkind == Q_SHADOW, id);
