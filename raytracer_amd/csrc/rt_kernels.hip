@@ -35,6 +35,9 @@ namespace rtd {
 // (1), C2 2.58 -> 2.12 ms and C3 19.3 -> 12.1 ms — lanes that start together stay in the same kind of
 // phase (trace, shadow 0, shadow 1 ...), so a resolve phase runs one branch instead of all of them,
 // which is worth more than the idle lanes cost
+#ifndef RT_JULIA_SHADER_PRIO
+#define RT_JULIA_SHADER_PRIO 0
+#endif
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 64
 #endif
@@ -1219,7 +1222,7 @@ template <bool STATS>
 RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n) {
     const int lane = threadIdx.x & 63;
     bool has = false, busy = false;
-    unsigned owner = 0, jidx = 0, jstep = 0, it = 0, okind = 0;
+    unsigned owner = 0, jidx = 0, jstep = 0, it = 0, okind = 0, prev_it = 0;
     V3 p = {0, 0, 0}, d = {0, 0, 0};
     JuliaPk s = julia_pk_begin({0, 0, 0, 0});
     PkF2 cp = {0, 0}, cq = {0, 0};
@@ -1351,6 +1354,13 @@ RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n) {
         bool converged = false, miss_t = false, miss_s = false;
         if (has && !busy) {
             bump<STATS>(n, C_JULIA_STEPS);
+            if (STATS) {
+                const int b = it <= 1u ? 0 : it <= 2u ? 1 : it <= 4u ? 2 : it <= 8u ? 3 : it <= 16u ? 4 : it <= 32u ? 5 : 6;
+                n.v[D_STEP_BLOCKS_1 + b]++;
+                n.v[D_STEP_BLOCK_SUM] += it;
+                if (jstep > 0u && (prev_it <= 4u) != (it <= 4u)) n.v[D_STEP_CLASS_SWITCH]++;
+                prev_it = it;
+            }
             const int r = julia_advance(julia_distance_tail_march(s.m2, s.d2), p, d, jstep);
             if (r == 0) {
                 s = julia_pk_begin({p.x, p.y, p.z, cut});
@@ -1415,6 +1425,9 @@ RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob&
         if (got == 0u) continue;
         patience = 0;
         watch.armed = false;
+#if RT_JULIA_SHADER_PRIO
+        __builtin_amdgcn_s_setprio(RT_JULIA_SHADER_PRIO);     // a batch in hand: the marchers on this SIMD wait for what it produces
+#endif
         const bool mine = static_cast<unsigned>(lane) < got;
         Lane L;
         L.state = S_IDLE;
@@ -1513,6 +1526,9 @@ RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob&
         const unsigned n_died = static_cast<unsigned>(__popcll(__ballot(died)));
         if (n_died != 0u && lane == 0) __hip_atomic_fetch_add(&sh.dead, n_died, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         beat(sh);
+#if RT_JULIA_SHADER_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         charge(D_QUERY_CYCLES);
     }
 }

@@ -239,6 +239,8 @@ enum CounterSlot : int {
     D_QUERY_CYCLES, D_MARCH_CYCLES, D_NORMAL_CYCLES, D_RESOLVE_CYCLES, D_TRI_CYCLES, D_SPHERE_CYCLES,
     D_R_NODE_CYCLES, D_R_LIGHT_CYCLES, D_R_SHADOWSETUP_CYCLES, D_R_FRESNEL_CYCLES, D_R_RETURN_CYCLES, D_R_FETCH_CYCLES,
     D_M_TAIL_CYCLES, D_M_IDLE_CYCLES, D_M_REFILL_CYCLES, D_T_WAIT_CYCLES, D_M_TAIL_BLOCKS, D_M_TAIL_LANES,
+    D_STEP_BLOCKS_1, D_STEP_BLOCKS_2, D_STEP_BLOCKS_4, D_STEP_BLOCKS_8, D_STEP_BLOCKS_16, D_STEP_BLOCKS_32, D_STEP_BLOCKS_MORE,   // march steps by estimator blocks of four
+    D_STEP_CLASS_SWITCH, D_STEP_BLOCK_SUM,   // steps whose class (<= 4 blocks or more) differs from the ray's previous step; total blocks
     D_RESOLVE_MIXED, D_RESOLVE_MINORITY_LANES,   // trace_kernel: resolve phases holding both ray results and shadow results; lanes of the rarer kind in them
     C_COUNT
 };

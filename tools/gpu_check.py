@@ -48,14 +48,15 @@ def main():
         if args.stats:
             print("  hip stats", {k: v for k, v in st.as_dict().items() if v}, flush=True)
             import ctypes as C
-            words = (C.c_uint64 * 64)()
-            nw = capi.hip_lib().rt_debug_counters(ctx._ctx, words, 64)
+            words = (C.c_uint64 * 96)()
+            nw = capi.hip_lib().rt_debug_counters(ctx._ctx, words, 96)
             names = ["query_phases", "query_lanes", "march_phases", "march_lanes", "normal_phases", "normal_lanes",
                      "resolve_phases", "resolve_lanes", "de_wave_iter_slots", "query_cycles", "march_cycles",
                      "normal_cycles", "resolve_cycles", "tri_cycles", "sphere_cycles",
                      "r_node", "r_light", "r_shadowsetup", "r_fresnel", "r_return", "r_fetch",
                      "m_tail_cycles", "m_idle_cycles", "m_refill_cycles", "t_wait_cycles", "m_tail_blocks", "m_tail_lanes",
-                     "resolve_mixed", "resolve_minority_lanes"]
+                     "step_blocks_1", "step_blocks_2", "step_blocks_4", "step_blocks_8", "step_blocks_16", "step_blocks_32", "step_blocks_more",
+                     "step_class_switch", "step_block_sum", "resolve_mixed", "resolve_minority_lanes"]
             dbg = dict(zip(names, list(words)[16:nw]))
             print("  scheduler", dbg, flush=True)
             for ph in ("query", "march", "normal", "resolve"):
