@@ -1248,6 +1248,10 @@ RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n) {
             const U4 flags = *reinterpret_cast<volatile U4*>(&sh.dead);              // dead, abort, heartbeat
             if (flags.y != 0u) break;
             const unsigned n_conv = ctl.w - ctl.z, n_jobs = ctl.y - ctl.x;
+            if (STATS && lane == 0) {
+                n.v[D_MARCH_POLLS]++;
+                n.v[D_MARCH_HAS_SUM] += static_cast<unsigned long long>(n_has0);
+            }
             // ---- finish converged jobs: a full batch at once, a partial one when there is little else to do
             if (n_conv >= 64u || (n_conv > 0u && n_has0 < RT_JULIA_NORMAL_IDLE && n_jobs == 0u)) {
                 unsigned first = 0;
@@ -1411,6 +1415,13 @@ RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob&
         const U4 flags = *reinterpret_cast<volatile U4*>(&sh.dead);           // dead, abort, heartbeat
         if (flags.y != 0u || flags.x >= static_cast<unsigned>(kPoolCtx)) break;
         const unsigned n_t = ctl_r.y - ctl_r.x, n_s = ctl_r.w - ctl_r.z, n_jobs = ctl_m.y - ctl_m.x;
+        if (STATS && lane == 0) {
+            n.v[D_RING_SAMPLES]++;
+            n.v[D_RING_MARCH_SUM] += n_jobs;
+            n.v[D_RING_NORMAL_SUM] += ctl_m.w - ctl_m.z;
+            n.v[D_RING_READY_T_SUM] += n_t;
+            n.v[D_RING_READY_S_SUM] += n_s;
+        }
         const int r = n_t >= n_s ? R_READY_T : R_READY_S;
         const unsigned n_ready = n_t >= n_s ? n_t : n_s;
         // a full batch at once; a partial one when the marchers are about to run out of jobs, or after a while

@@ -241,6 +241,8 @@ enum CounterSlot : int {
     D_M_TAIL_CYCLES, D_M_IDLE_CYCLES, D_M_REFILL_CYCLES, D_T_WAIT_CYCLES, D_M_TAIL_BLOCKS, D_M_TAIL_LANES,
     D_STEP_BLOCKS_1, D_STEP_BLOCKS_2, D_STEP_BLOCKS_4, D_STEP_BLOCKS_8, D_STEP_BLOCKS_16, D_STEP_BLOCKS_32, D_STEP_BLOCKS_MORE,   // march steps by estimator blocks of four
     D_STEP_CLASS_SWITCH, D_STEP_BLOCK_SUM,   // steps whose class (<= 4 blocks or more) differs from the ray's previous step; total blocks
+    D_RING_SAMPLES, D_RING_MARCH_SUM, D_RING_NORMAL_SUM, D_RING_READY_T_SUM, D_RING_READY_S_SUM, D_MARCH_HAS_SUM,   // ring lengths as the shader waves see them; lanes holding a job when a marcher polls
+    D_MARCH_POLLS,
     D_RESOLVE_MIXED, D_RESOLVE_MINORITY_LANES,   // trace_kernel: resolve phases holding both ray results and shadow results; lanes of the rarer kind in them
     C_COUNT
 };
