@@ -170,6 +170,8 @@ typedef struct rt_stats {
     uint64_t texture_lookups;
     uint64_t bvh_node_visits;
     double   kernel_ms;             /* device time of the last call's kernels (HIP events) */
+    uint64_t shadow_rays_elided;    /* of shadow_rays: towards lights that can only add +-0 (surface with kd == ks == 0); a launch
+                                       without counters does not trace them (RT_OPT_ELIDE_UNLIT_SHADOWS), a counters launch does */
 } rt_stats;
 
 /* ---- context -------------------------------------------------------------------------------- */
@@ -198,8 +200,13 @@ enum {
                                    surplus with atomics and sizes the buffer for the next pass; rt_photon_generate reruns. */
     RT_OPT_PHOTON_RECORDS = 5,  /* capacity of that record buffer in deposits; 0 (default) = a sixteenth of the root photons,
                                    at least 262144; grows by itself as described above */
-    RT_OPT_DEBUG_FORCE_ABORT = 6 /* test hook, 0/1: the Julia kernel's first workgroup raises its watchdog flag at once, as a wave
+    RT_OPT_DEBUG_FORCE_ABORT = 6, /* test hook, 0/1: the Julia kernel's first workgroup raises its watchdog flag at once, as a wave
                                    stuck on the job queues would: the launch is then reported as abandoned (RT_ERR_HIP) */
+    RT_OPT_ELIDE_UNLIT_SHADOWS = 7 /* 1 (default): a shadow ray towards a light that can only add +-0 to the radiance — the surface
+                                   has kd == 0 and ks == 0 (mirror, clear glass) and no factor is infinite or NaN — is not
+                                   traced (the reference casts it and multiplies the result by zero, src/raytracer.cpp:214-235);
+                                   same picture bit for bit.  rt_stats.shadow_rays still counts it, shadow_rays_elided says how
+                                   many.  0: trace every shadow ray. */
 };
 int rt_set_option(rt_ctx* ctx, int option, int64_t value);
 

@@ -129,6 +129,7 @@ struct rt_ctx {
     unsigned long long* h_status = nullptr;     // pinned copy of d_queue[1], written by the stream after every render launch
     bool status_pending = false;                // a render launch whose watchdog word has not been looked at yet
     bool debug_force_abort = false;             // RT_OPT_DEBUG_FORCE_ABORT
+    bool elide_unlit_shadows = true;            // RT_OPT_ELIDE_UNLIT_SHADOWS
     unsigned long long* status_flag = nullptr;  // device word the pending status was copied from (cleared once seen)
     unsigned char* noalloc_scratch = nullptr;   // address of `scratch` on this context's device (hipGetSymbolAddress)
     // persistent grid of the render kernels for the uploaded scene ([0] plain, [1] counters build): asked once per upload
@@ -335,6 +336,7 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     job.queue_head = ws.queue;
     job.counters = ws.counters;
     job.debug_abort = ctx->debug_force_abort ? 1u : 0u;
+    job.elide_unlit = (ctx->elide_unlit_shadows && !stats) ? 1u : 0u;
     if (ctx->upload_in_flight && stream != nullptr) RT_HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ev_upload, 0));   // the scene's copy ran on the default stream
     if (fixed != nullptr) {
         // the fixed workspace is shared by every call on this GPU and keeps the last call's contents: both queue
@@ -535,6 +537,7 @@ int read_stats(rt_ctx* ctx, rt_stats* out) {
     out->fresnel_evals = c[C_FRESNEL];
     out->texture_lookups = c[C_TEXTURE_LOOKUPS];
     out->bvh_node_visits = c[C_BVH_NODE_VISITS];
+    out->shadow_rays_elided = c[C_SHADOW_ELIDED];
     if (ctx->events_pending) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) == hipSuccess) out->kernel_ms = ms;
@@ -710,6 +713,7 @@ int rt_set_option(rt_ctx* ctx, int option, int64_t value) {
             ctx->dep_capacity = static_cast<uint32_t>((value + 63) & ~63ll);
             return RT_OK;
         case RT_OPT_DEBUG_FORCE_ABORT: ctx->debug_force_abort = value != 0; return RT_OK;
+        case RT_OPT_ELIDE_UNLIT_SHADOWS: ctx->elide_unlit_shadows = value != 0; return RT_OK;
         default: return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
     }
 }
@@ -791,6 +795,15 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
         if (lights[i].type == 1) ctx->point_lights.push_back(i);
     }
     sc.n_lights = d->n_lights;
+    // DevMaterial::unlit / resolve_lane: a light is benign when nothing about it can turn a product with zero into a NaN
+    auto tame = [](float v) { return std::fabs(v) <= 1e18f; };     // (false for NaN)
+    sc.lights_benign = 1u;
+    for (const DevLight& l : lights) {
+        bool ok = tame(l.power[0]) && tame(l.power[1]) && tame(l.power[2]) && tame(l.position[0]) && tame(l.position[1]) && tame(l.position[2]);
+        if (l.type == 0) ok = ok && (l.position[0] != 0.0f || l.position[1] != 0.0f || l.position[2] != 0.0f) &&
+                              std::fabs(l.position[0]) + std::fabs(l.position[1]) + std::fabs(l.position[2]) >= 1e-18f;
+        if (!ok) sc.lights_benign = 0u;
+    }
 
     // ---- materials, textures -----------------------------------------------------------------------
     std::vector<DevMaterial> mats(d->n_materials);
@@ -803,7 +816,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
         o.reflectance = m.reflectance; o.transmittance = m.transmittance;
         o.refr_re = m.refraction_re; o.refr_im = m.refraction_im; o.dispersion = m.dispersion;
         o.refr_norm = m.refraction_re * m.refraction_re + m.refraction_im * m.refraction_im;   // std::norm
-        o.pad = 0.0f;
+        o.unlit = (m.kd == 0.0f && m.ks == 0.0f && m.exponent >= 0.0f && m.exponent <= 1e6f && tame(m.color[0]) && tame(m.color[1]) && tame(m.color[2])) ? 1u : 0u;
     }
     std::vector<DevTexture> texs(d->n_textures);
     std::vector<uint32_t> texels;     // RGBA8 as given; the kernels form u8 / 255.0f themselves (rt_intersect.h: unorm8)

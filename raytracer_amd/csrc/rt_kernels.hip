@@ -710,6 +710,29 @@ RT_DEV void resolve_lane(const DevScene& sc, const ShadeTables& T, const DevJob&
 
     mark<STATS>(n, t_sec, L.qkind == Q_TRACE ? D_R_NODE_CYCLES : D_R_LIGHT_CYCLES);
     if (!returning && !lights_done) {
+        // Lights that can only add +-0.  On a surface with kd == 0 and ks == 0 (a mirror, clear glass) the reference
+        // still casts a shadow ray per light and then adds power*colour*lambert*0 + power*pow(..)*0 if it is not
+        // blocked (src/raytracer.cpp:214-235): +-0 onto a sum that is +0 or non-zero, i.e. nothing, blocked or not —
+        // provided none of the factors is infinite or NaN, which is what DevMaterial::unlit, DevScene::lights_benign
+        // and the checks below establish (finite point and unit normal, a light direction of finite non-zero
+        // length; then lambert, the reflected direction and pow's base are finite and pow <= e^0.25).  Such rays
+        // are not traced.  A counters launch traces them (its counts are those of the reference's formulation)
+        // and reports how many the plain launch skips.
+        if (L.li < sc.n_lights && sc.lights_benign != 0u && T.materials[T.object_material[L.n_obj]].unlit != 0u &&
+            fabsf(L.n_point.x) + fabsf(L.n_point.y) + fabsf(L.n_point.z) < __builtin_inff() &&
+            fabsf(L.n_normal.x) + fabsf(L.n_normal.y) + fabsf(L.n_normal.z) < __builtin_inff()) {
+            while (L.li < sc.n_lights) {
+                const DevLight& light = T.lights[L.li];
+                if (light.type != 0) {
+                    const V3 d = v3(light.position[0], light.position[1], light.position[2]) - L.n_point;
+                    const float dd = dot(d, d);
+                    if (!(dd > 0.0f && dd < __builtin_inff())) break;
+                }
+                bump<STATS>(n, C_SHADOW_ELIDED);
+                if (job.elide_unlit == 0u) break;
+                L.li++;
+            }
+        }
         if (L.li < sc.n_lights) {
             begin_shadow(T, L);
             mark<STATS>(n, t_sec, D_R_SHADOWSETUP_CYCLES);

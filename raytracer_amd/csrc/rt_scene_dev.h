@@ -70,7 +70,7 @@ struct DevMaterial {
     float reflectance, transmittance;
     float refr_re, refr_im, dispersion;
     float refr_norm;         // re*re + im*im (std::norm)
-    float pad;
+    uint32_t unlit;          // 1: kd == 0 and ks == 0 with tame colour and exponent: every light adds exactly +-0 here (resolve_lane)
 };
 struct DevTexture {
     uint32_t width, height;
@@ -151,6 +151,7 @@ struct DevScene {
     const unsigned char* shade_blob;
     uint32_t shade_blob_bytes;
     uint32_t shade_blob_in_lds;        // 0/1, decided by the host from the blob size
+    uint32_t lights_benign;            // 0/1: every light has a tame power and position (see DevMaterial::unlit)
     uint32_t bvh_lds_stack_entries;    // per-lane BVH stack entries kept in LDS (behind the blob copy); deeper ones go to scratch
 
     float4* photon_atlas;              // [n_slots][size][size]
@@ -176,6 +177,7 @@ struct DevJob {
     uint32_t static_blocks;      // 64-id blocks every wave owns outright: wave w of n_waves owns blocks w, w + n_waves, ...
     uint32_t n_waves;
     uint64_t dyn_base;           // first id handed out through queue_head
+    uint32_t elide_unlit;        // RT_OPT_ELIDE_UNLIT_SHADOWS and no counters: shadow rays whose light can only add +-0 are not traced
     uint32_t debug_abort;        // RT_OPT_DEBUG_FORCE_ABORT: trace_julia_kernel's first workgroup raises its watchdog flag at once
     uint32_t pad0;
 };
@@ -232,7 +234,7 @@ constexpr uint32_t kJuliaStaticLdsBytes = 160 * 1024;    // its static LDS (pool
 enum CounterSlot : int {
     C_PRIMARY = 0, C_SECONDARY, C_SHADOW, C_PHOTON_SEGMENTS, C_PHOTON_DEPOSITS, C_SPHERE_TESTS, C_TRIANGLE_TESTS,
     C_JULIA_QUERIES, C_JULIA_STEPS, C_JULIA_DE_ITERATIONS, C_JULIA_NORMALS, C_SHADED_HITS, C_PHONG_LIGHTS,
-    C_FRESNEL, C_TEXTURE_LOOKUPS, C_BVH_NODE_VISITS,
+    C_FRESNEL, C_TEXTURE_LOOKUPS, C_BVH_NODE_VISITS, C_SHADOW_ELIDED,
     // scheduler diagnostics (rt_debug_counters; not part of rt_stats)
     D_QUERY_PHASES, D_QUERY_LANES, D_MARCH_PHASES, D_MARCH_LANES, D_NORMAL_PHASES, D_NORMAL_LANES,
     D_RESOLVE_PHASES, D_RESOLVE_LANES, D_DE_WAVE_ITERS,

@@ -542,6 +542,36 @@ def test_depth_of_field(hip_ctx):
     assert abs(float(pictures[0][..., :3].mean()) - float(pictures[1][..., :3].mean())) < 0.01
 
 
+@pytest.mark.parametrize("rel,t", [("examples2/8_fresnel.xml", 0.0), ("examples3/103_caustic_animation.xml", 0.5),
+                                   ("examples3/101_julia_shiny.xml", 0.0)])
+def test_shadow_rays_that_can_only_add_zero_are_not_traced(hip_ctx, rel, t):
+    """On a surface with kd == ks == 0 (the glass and mirror objects of C3, C4, C5) the reference casts a shadow ray per
+    light and multiplies what it finds by zero.  The plain launch skips those rays (RT_OPT_ELIDE_UNLIT_SHADOWS), the
+    counters launch traces them and says how many there are: same float picture bit for bit, with the option on or off,
+    as the oracle's, and the plain launch is not slower."""
+    sc = capi.Scene(scene_path(rel), t)
+    if sc.desc.n_julias > 0:
+        sc.set_camera(240, 150, 0)
+    hip_ctx.upload(sc)
+    hip_ctx.set_option(capi.RT_OPT_COLLECT_STATS, 1)
+    hip_ctx.photon_generate()
+    counted, st = hip_ctx.render()
+    hip_ctx.set_option(capi.RT_OPT_COLLECT_STATS, 0)
+    assert 0 < st.shadow_rays_elided < st.shadow_rays
+    try:
+        pictures = []
+        for on in (1, 0):
+            hip_ctx.set_option(capi.RT_OPT_ELIDE_UNLIT_SHADOWS, on)
+            pictures.append(hip_ctx.render()[0])
+    finally:
+        hip_ctx.set_option(capi.RT_OPT_ELIDE_UNLIT_SHADOWS, 1)
+    ph = oracle_lib.Photons(sc) if sc.desc.photon_steps > 0 else None
+    ref, ost = oracle_lib.render(sc, ph, threads=16)
+    assert st.shadow_rays == ost.shadow_rays
+    for img in pictures + [counted]:
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
 def test_depth_of_field_against_the_reference_statistically(hip_ctx):
     """The HIP picture of examples2/7_dof.xml (full size, 7x7 supersampling) against the reference's own two runs
     (tests/golden/x_dof_run{1,2}.png): PSNR no more than 0.5 dB below what the runs reach against each other, and
