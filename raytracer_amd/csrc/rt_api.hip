@@ -38,8 +38,11 @@ constexpr int kFrameFieldsHost = 11;
 constexpr uint32_t kBvhLdsStackEntries = 16;   // 16 KB per workgroup of 256 lanes: with the 36 KB of frame tops and parked node state, 3 blocks per CU still fit
 // dynamic LDS of trace_kernel / photon_kernel: [copy of the shade blob, if small][BVH stack columns, if the scene has a BVH]
 static size_t dynamic_lds_bytes(const rtd::DevScene& sc) {
-    return (sc.shade_blob_in_lds ? ((size_t(sc.shade_blob_bytes) + 15) & ~size_t(15)) : 0) + size_t(sc.bvh_lds_stack_entries) * 256 * sizeof(uint32_t);
+    return (sc.shade_blob_in_lds ? ((size_t(sc.shade_blob_bytes) + 15) & ~size_t(15)) : 0) + size_t(sc.bvh_lds_stack_entries) * 256 * sizeof(uint32_t) +
+           (sc.frame_slots_in_lds == 2 ? size_t(kFrameFieldsHost) * 256 * sizeof(float) : 0);
 }
+constexpr size_t kTraceStaticLdsBytes = (size_t(kFrameFieldsHost) + 26) * 256 * sizeof(float);   // first frame slot + parked state (rt_kernels.hip)
+constexpr size_t kLdsPerBlockFor3 = 160 * 1024 / 3 - 512;                                        // 3 workgroups per CU
 constexpr size_t kMaxLdsBlobBytes = 16 * 1024;   // + 11 KB of frame tops + 25 KB of parked node state: 3 blocks per CU within the 160 KB LDS
 constexpr int kFrameRecordWordsHost = 12;       // trace_julia_kernel keeps every frame as a 48-byte record of its own
 constexpr int kJuliaBlockThreads = kJuliaWaves * 64, kJuliaShaderWavesHost = kJuliaWaves - kJuliaMarcherWaves;
@@ -1105,6 +1108,12 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
         if ((rc = grow(ctx, ctx->atlas, atlas_bytes)) != RT_OK) return rc;
         RT_HIP_TRY(ctx, hipMemsetAsync(ctx->atlas.ptr, 0, atlas_bytes, nullptr));
         sc.photon_atlas = static_cast<float4*>(ctx->atlas.ptr);
+    }
+    // a second frame slot per lane in LDS when three workgroups per CU still fit with it (TopInLds)
+    sc.frame_slots_in_lds = 1;
+    if (sc.n_julias == 0) {
+        sc.frame_slots_in_lds = 2;
+        if (kTraceStaticLdsBytes + dynamic_lds_bytes(sc) > kLdsPerBlockFor3) sc.frame_slots_in_lds = 1;
     }
     {
         // persistent-grid sizes of the render kernels for this scene (the LDS copy of the shade blob decides), asked

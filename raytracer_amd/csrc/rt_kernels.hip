@@ -110,6 +110,7 @@ struct Lane {
     unsigned li;
     // sample
     unsigned sp;             // frames on the stack == depth of the current node
+    unsigned resident;       // TopInLds: lowest frame held in LDS
     float wavelength;
     int hue;                 // -1 without dispersion
     unsigned long long out_slot;
@@ -444,21 +445,33 @@ struct FrameRef {
 //   FramesInHbm (trace_julia_kernel's ray pool): a context is handled by whichever wave pops it, so every frame is a
 //              48-byte record of its own in HBM, [context][frame][field]: a lane touches one or two cache lines per push/pop.
 struct TopInLds {
-    float* top;              // this lane's column of the LDS array
+    float* top;              // this lane's column of the first LDS slot: field c at top[c * top_stride]
+    float* top2;             // ... of the second slot (unused with one slot)
     unsigned top_stride;
+    unsigned slot_mask;      // slots - 1: 0 or 1
     FrameRef below;
-    RT_DEV float get(unsigned, int c) const { return top[c * top_stride]; }
-    RT_DEV void set(unsigned, int c, float v) const { top[c * top_stride] = v; }
-    RT_DEV void before_push(unsigned f) const {      // frame f becomes the top: the old top moves to HBM
-        if (f > 0) {
+    unsigned* resident;      // the lane's lowest frame that is in LDS (frames resident .. resident + slots - 1 are)
+    RT_DEV float* slot(unsigned f) const { return (f & slot_mask) != 0u ? top2 : top; }
+    RT_DEV float get(unsigned f, int c) const { return slot(f)[c * top_stride]; }
+    RT_DEV void set(unsigned f, int c, float v) const { slot(f)[c * top_stride] = v; }
+    // With two slots a ray tree that goes up and down between two neighbouring depths (the common case near its
+    // leaves) touches no HBM at all; a frame moves out only when the tree goes two deeper than the oldest resident
+    // frame and comes back only when the tree returns below it.
+    RT_DEV void before_push(unsigned f) const {      // frame f becomes the top
+        if (f > *resident + slot_mask) {
+            const unsigned out = *resident;
+            const float* from = slot(out);
 #pragma unroll
-            for (int c = 0; c < kFrameFields; c++) below.at(f - 1, c) = top[c * top_stride];
+            for (int c = 0; c < kFrameFields; c++) below.at(out, c) = from[c * top_stride];
+            *resident = out + 1u;
         }
     }
-    RT_DEV void after_pop(unsigned f) const {        // frame f is gone: frame f-1 comes back as the top
-        if (f > 0) {
+    RT_DEV void after_pop(unsigned f) const {        // frame f is gone: frame f-1 is the top again
+        if (f > 0 && f - 1 < *resident) {
+            float* to = slot(f - 1);
 #pragma unroll
-            for (int c = 0; c < kFrameFields; c++) top[c * top_stride] = below.at(f - 1, c);
+            for (int c = 0; c < kFrameFields; c++) to[c * top_stride] = below.at(f - 1, c);
+            *resident = f - 1;
         }
     }
 };
@@ -567,6 +580,7 @@ RT_DEV bool start_sample(const DevScene& sc, const DevJob& job, unsigned long lo
     V3 origin = xform_point(sc.cam, v3(0.0f, 0.0f, 0.0f));
     origin = {origin.x + lx, origin.y + ly, origin.z};
     L.sp = 0;
+    L.resident = 0;
     L.hue = sc.dispersion ? static_cast<int>(hue) : -1;
     L.wavelength = sc.dispersion ? (static_cast<float>(hue) * 45.0f) / 180.0f - 1.0f : 0.0f;
     L.out_slot = static_cast<unsigned long long>(s) * job.n_pixels + static_cast<unsigned long long>(yc) * sc.width + x;
@@ -840,12 +854,12 @@ RT_DEV void flush_counters(const Counters& n, unsigned long long* out) {
 // budget: ~6 GB of HBM writes per C3 frame, since the scratch of 3072 waves does not stay in L2); trace_kernel
 // parks it in LDS at the end of every resolve phase and takes it back at the start of the next one, for all lanes
 // alike (uniform control flow), so that the registers are dead in between.
-constexpr int kParkWords = 25;
+constexpr int kParkWords = 26;
 RT_DEV void park_node(float* col, const Lane& L) {
     const float w[kParkWords] = {L.n_point.x, L.n_point.y, L.n_point.z, L.n_normal.x, L.n_normal.y, L.n_normal.z, L.n_dir.x, L.n_dir.y, L.n_dir.z,
                                  L.n_ph.x, L.n_ph.y, L.n_cos, __uint_as_float(L.n_obj), L.acc[0], L.acc[1], L.acc[2], L.matcol[0], L.matcol[1], L.matcol[2],
                                  __uint_as_float(L.li), __uint_as_float(L.sp), L.wavelength, __int_as_float(L.hue),
-                                 __uint_as_float(static_cast<unsigned>(L.out_slot)), __uint_as_float(static_cast<unsigned>(L.out_slot >> 32))};
+                                 __uint_as_float(static_cast<unsigned>(L.out_slot)), __uint_as_float(static_cast<unsigned>(L.out_slot >> 32)), __uint_as_float(L.resident)};
 #pragma unroll
     for (int i = 0; i < kParkWords; i++) col[i * 256] = w[i];
 }
@@ -870,6 +884,7 @@ RT_DEV void unpark_node(const float* col, Lane& L) {
     L.wavelength = w[21];
     L.hue = __float_as_int(w[22]);
     L.out_slot = static_cast<unsigned long long>(__float_as_uint(w[23])) | (static_cast<unsigned long long>(__float_as_uint(w[24])) << 32);
+    L.resident = __float_as_uint(w[25]);
 }
 
 // ---- the render kernel (scenes without Julia sets) ----------------------------------------------------
@@ -901,10 +916,15 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
     __shared__ float top_store[kFrameFields * 256];
     __shared__ float park_store[kParkWords * 256];
     float* const park = park_store + threadIdx.x;
-    const TopInLds frames = {top_store + threadIdx.x, 256u, stack};
+    // a second slot per lane behind the blob copy and the BVH stack columns, when the host found room for it
+    float* const second_slot = reinterpret_cast<float*>(lds_blob + (sc.shade_blob_in_lds ? ((sc.shade_blob_bytes + 15u) & ~15u) : 0u) +
+                                                        sc.bvh_lds_stack_entries * 256u * sizeof(unsigned)) + threadIdx.x;
+    const bool two_slots = sc.frame_slots_in_lds == 2u;
+    const TopInLds frames = {top_store + threadIdx.x, second_slot, 256u, two_slots ? 1u : 0u, stack, &L.resident};
     L.state = S_RESOLVE;       // "resolve" of a lane without a sample = fetch one
     L.qkind = -1;
     L.sp = 0;
+    L.resident = 0;
     L.jidx = 0;
     L.jstep = 0;
     L.n_point = L.n_normal = L.n_dir = v3(0.0f, 0.0f, 0.0f);
