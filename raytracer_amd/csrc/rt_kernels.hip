@@ -939,6 +939,9 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
     bool fresh = true;         // lane holds no sample yet
     bool want = false;         // lane is idle and waits for the next refill
     WaveIds wave_ids = wave_ids_begin(gid, job.n_waves, job.static_blocks);
+#ifdef RT_PHASE_TIMING
+    unsigned long long phase_clocks[4] = {0, 0, 0, 0};
+#endif
 
     for (;;) {
         // every lane alternates query -> resolve in lockstep
@@ -948,6 +951,9 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
         const int phase = any_query ? S_QUERY : S_RESOLVE;
 
         long long t_phase = 0, t_fetch_outer = 0;
+#ifdef RT_PHASE_TIMING      // developer build: phase clocks without the per-lane counters of the STATS build
+        if (!STATS) t_phase = __builtin_readcyclecounter();
+#endif
         if (STATS) {
             t_phase = clock64();
             const int base = phase == S_QUERY ? D_QUERY_PHASES : D_RESOLVE_PHASES;
@@ -1003,6 +1009,13 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
             }
             park_node(park, L);
         }
+#ifdef RT_PHASE_TIMING
+        if (!STATS) {
+            const unsigned long long dt = static_cast<unsigned long long>(__builtin_readcyclecounter() - t_phase);
+            phase_clocks[phase == S_QUERY ? 0 : 1] += dt;
+            if (phase == S_QUERY) phase_clocks[3]++;
+        }
+#endif
         if (STATS && phase == S_RESOLVE && (threadIdx.x & 63) == 0) n.v[D_R_FETCH_CYCLES] += static_cast<unsigned long long>(clock64() - t_fetch_outer);
         if (STATS && (threadIdx.x & 63) == 0) {
             const int slot = phase == S_QUERY ? D_QUERY_CYCLES : D_RESOLVE_CYCLES;
@@ -1010,6 +1023,14 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
         }
     }
     flush_counters<STATS>(n, job.counters);
+#ifdef RT_PHASE_TIMING
+    if (!STATS && (threadIdx.x & 63) == 0) {
+        atomicAdd(&job.counters[D_QUERY_CYCLES], phase_clocks[0]);
+        atomicAdd(&job.counters[D_RESOLVE_CYCLES], phase_clocks[1]);
+        atomicAdd(&job.counters[D_R_FETCH_CYCLES], phase_clocks[2]);
+        atomicAdd(&job.counters[D_QUERY_PHASES], phase_clocks[3]);
+    }
+#endif
 }
 
 // ---- the render kernel for scenes with Julia sets: a ray pool with queues by kind -----------------------
