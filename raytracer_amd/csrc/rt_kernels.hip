@@ -334,9 +334,14 @@ RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, const BvhS
                     // (t_slack: see query_bvh — the triangle test's distance and the slab's are different roundings)
                     const float t_slack = cb->slack;
                     const bool overlap = !(tnear > tfar * 1.000001f) && !(tfar < -t_slack) && !(tnear * 0.9999f - t_slack > L.qmax);
+                    if (STATS && (threadIdx.x & 63) == 0) n.v[D_CHUNK_TESTS]++;
                     if (!__any(act != 0u && overlap)) {
                         if (act != 0u) bump<STATS>(n, C_TRIANGLE_TESTS, count - i < RT_TRI_GROUP ? count - i : RT_TRI_GROUP);
                         continue;
+                    }
+                    if (STATS) {
+                        if ((threadIdx.x & 63) == 0) n.v[D_CHUNK_PASSED]++;
+                        if (act != 0u && overlap) n.v[D_CHUNK_LANES]++;
                     }
                 }
                 TriGeom g[RT_TRI_GROUP];
@@ -389,10 +394,12 @@ RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, const BvhS
                     const float slack = sb->slack_scale * (oo + sb->magnitude2);
                     const float lim = sb->radius2 + slack;
                     const bool miss = (cc - bb * bb > lim) || (cc > lim && (bb < 0.0f || bb - sb->radius > L.qmax * 1.001f + slack));
+                    if (STATS && (threadIdx.x & 63) == 0) n.v[D_SPHERE_CULLS]++;
                     if (!__any(act != 0u && !miss)) {
                         if (act != 0u) bump<STATS>(n, C_SPHERE_TESTS);
                         continue;
                     }
+                    if (STATS && (threadIdx.x & 63) == 0) n.v[D_SPHERE_PASSED]++;
                 }
                 if (act != 0u) {
                     bump<STATS>(n, C_SPHERE_TESTS);

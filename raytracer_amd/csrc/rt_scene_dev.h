@@ -246,6 +246,7 @@ enum CounterSlot : int {
     D_STEP_CLASS_SWITCH, D_STEP_BLOCK_SUM,   // steps whose class (<= 4 blocks or more) differs from the ray's previous step; total blocks
     D_RING_SAMPLES, D_RING_MARCH_SUM, D_RING_NORMAL_SUM, D_RING_READY_T_SUM, D_RING_READY_S_SUM, D_MARCH_HAS_SUM,   // ring lengths as the shader waves see them; lanes holding a job when a marcher polls
     D_MARCH_POLLS,
+    D_CHUNK_TESTS, D_CHUNK_PASSED, D_CHUNK_LANES, D_SPHERE_CULLS, D_SPHERE_PASSED,   // wave-level: chunk / sphere cull tests made, not culled; lanes overlapping a passed chunk
     D_RESOLVE_MIXED, D_RESOLVE_MINORITY_LANES,   // trace_kernel: resolve phases holding both ray results and shadow results; lanes of the rarer kind in them
     C_COUNT
 };

@@ -57,7 +57,8 @@ def main():
                      "m_tail_cycles", "m_idle_cycles", "m_refill_cycles", "t_wait_cycles", "m_tail_blocks", "m_tail_lanes",
                      "step_blocks_1", "step_blocks_2", "step_blocks_4", "step_blocks_8", "step_blocks_16", "step_blocks_32", "step_blocks_more",
                      "step_class_switch", "step_block_sum", "ring_samples", "ring_march_sum", "ring_normal_sum", "ring_ready_t_sum", "ring_ready_s_sum",
-                     "march_has_sum", "march_polls", "resolve_mixed", "resolve_minority_lanes"]
+                     "march_has_sum", "march_polls", "chunk_tests", "chunk_passed", "chunk_lanes", "sphere_culls", "sphere_passed",
+                     "resolve_mixed", "resolve_minority_lanes"]
             dbg = dict(zip(names, list(words)[17:nw]))
             print("  scheduler", dbg, flush=True)
             for ph in ("query", "march", "normal", "resolve"):
