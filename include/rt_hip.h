@@ -190,7 +190,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* desc);
 /* Options that are not part of the scene (never read from scene XML). */
 enum {
     RT_OPT_COLLECT_STATS = 1,   /* 0/1: fill rt_stats counters (slower kernels); default 0 */
-    RT_OPT_BVH_MIN_TRIANGLES = 2,/* BVH traversal for runs of consecutive triangle objects of at least this many (default 256);
+    RT_OPT_BVH_MIN_TRIANGLES = 2,/* BVH traversal for runs of consecutive triangle objects of at least this many (default 48);
                                     runs holding a zero-area triangle always keep the sequential scan */
     RT_OPT_DOF_SEED = 3,        /* seed of the counter-based lens RNG; default 0 */
     RT_OPT_PHOTON_ORDER = 4,    /* 1 (default): photon deposits are recorded, sorted and summed per texel in the order of the

@@ -20,7 +20,7 @@ RT_HUE_INT_ABS, RT_HUE_FLOAT_ABS = 0, 1
 RT_OPT_COLLECT_STATS, RT_OPT_BVH_MIN_TRIANGLES, RT_OPT_DOF_SEED, RT_OPT_PHOTON_ORDER, RT_OPT_PHOTON_RECORDS = 1, 2, 3, 4, 5
 RT_OPT_DEBUG_FORCE_ABORT = 6
 RT_OPT_ELIDE_UNLIT_SHADOWS = 7
-RT_DEFAULT_BVH_MIN_TRIANGLES = 256
+RT_DEFAULT_BVH_MIN_TRIANGLES = 48
 FLT_MAX = float(np.finfo(np.float32).max)
 
 

@@ -110,7 +110,8 @@ struct rt_ctx {
     const uint32_t* d_point_lights = nullptr;
     // options
     bool collect_stats = false;
-    int64_t bvh_min_triangles = 256;  // below this the chunk-culled scan wins (C2, 64 triangles: 2.9 ms against 3.9 ms with the BVH)
+    int64_t bvh_min_triangles = 48;   // measured: C2 (one run of 64 triangles) 1.95 ms with the BVH against 2.04 ms with the chunk-culled scan;
+                                      // C5 (20 triangles) 0.90 against 0.79 ms, so short runs keep the scan
     uint32_t dof_seed = 0;
     bool photon_order = true;          // RT_OPT_PHOTON_ORDER: deposits summed in the reference's order
     // ordered photon deposits (rt_photon_order.hip)

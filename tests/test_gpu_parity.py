@@ -666,13 +666,20 @@ def test_culling_never_changes_the_answer_far_from_the_origin(tmp_path):
     assert sc.desc.n_spheres == 10 and sc.desc.n_triangles >= 70
     ctx = capi.Context(0)
     ctx.set_option(capi.RT_OPT_COLLECT_STATS, 1)
-    ctx.upload(sc)
-    img, st = ctx.render()
     ref, ost = oracle_lib.render(sc, None, threads=16)
-    assert np.array_equal(np.isnan(img), np.isnan(ref))
-    assert np.array_equal(np.nan_to_num(img).view(np.uint32), np.nan_to_num(ref).view(np.uint32))
-    for k in ("primary_rays", "secondary_rays", "shadow_rays", "sphere_tests", "triangle_tests", "shaded_hits"):
-        assert getattr(st, k) == getattr(ost, k), k
+    # with the scan (chunk culling) for every run, and as configured by default (the 70-triangle run behind the BVH)
+    for bvh_min in (1 << 40, capi.RT_DEFAULT_BVH_MIN_TRIANGLES):
+        ctx.set_option(capi.RT_OPT_BVH_MIN_TRIANGLES, bvh_min)
+        ctx.upload(sc)
+        img, st = ctx.render()
+        assert np.array_equal(np.isnan(img), np.isnan(ref))
+        assert np.array_equal(np.nan_to_num(img).view(np.uint32), np.nan_to_num(ref).view(np.uint32))
+        for k in ("primary_rays", "secondary_rays", "shadow_rays", "sphere_tests", "triangle_tests", "shaded_hits"):
+            if k == "triangle_tests" and st.bvh_node_visits > 0:
+                assert st.triangle_tests < ost.triangle_tests
+                continue
+            assert getattr(st, k) == getattr(ost, k), k
+        assert (st.bvh_node_visits > 0) == (bvh_min == capi.RT_DEFAULT_BVH_MIN_TRIANGLES)
     assert st.secondary_rays > 0 and st.shadow_rays > st.primary_rays
     ctx.close()
 
