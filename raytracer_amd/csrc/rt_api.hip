@@ -39,7 +39,7 @@ constexpr uint32_t kBvhLdsStackEntries = 16;   // 16 KB per workgroup of 256 lan
 // dynamic LDS of trace_kernel / photon_kernel: [copy of the shade blob, if small][BVH stack columns, if the scene has a BVH]
 static size_t dynamic_lds_bytes(const rtd::DevScene& sc) {
     return (sc.shade_blob_in_lds ? ((size_t(sc.shade_blob_bytes) + 15) & ~size_t(15)) : 0) + size_t(sc.bvh_lds_stack_entries) * 256 * sizeof(uint32_t) +
-           (sc.frame_slots_in_lds == 2 ? size_t(kFrameFieldsHost) * 256 * sizeof(float) : 0);
+           (sc.frame_slots_in_lds == 2 ? size_t(kFrameFieldsHost) * 256 * sizeof(float) : 0) + size_t(sc.bvh_records_in_lds) * sizeof(rtd::DevBvhPair);
 }
 constexpr size_t kTraceStaticLdsBytes = (size_t(kFrameFieldsHost) + 26) * 256 * sizeof(float);   // first frame slot + parked state (rt_kernels.hip)
 constexpr size_t kLdsPerBlockFor3 = 160 * 1024 / 3 - 512;                                        // 3 workgroups per CU
@@ -1057,6 +1057,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
     sc.bvh_nodes = nullptr;
     sc.bvh_prims = nullptr;
     sc.bvh_lds_stack_entries = 0;
+    sc.bvh_records_in_lds = 0;
+    size_t total_bvh_records = 0;
     {
         // GPU-built BVH for every triangle run that is long enough (RT_OPT_BVH_MIN_TRIANGLES)
         // A run qualifies only if every triangle has a finite, non-zero area: a zero-area triangle makes
@@ -1094,6 +1096,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
             }
             sc.bvh_nodes = static_cast<const DevBvhPair*>(d_nodes);
             sc.bvh_lds_stack_entries = sc.shade_blob_in_lds ? 8 : kBvhLdsStackEntries;
+            total_bvh_records = total_nodes;
             // the runs table was uploaded before the kinds changed: refresh it
             RT_HIP_TRY(ctx, hipMemcpy(const_cast<DevRun*>(sc.runs), runs.data(), runs.size() * sizeof(DevRun), hipMemcpyHostToDevice));
         }
@@ -1110,8 +1113,18 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
         RT_HIP_TRY(ctx, hipMemsetAsync(ctx->atlas.ptr, 0, atlas_bytes, nullptr));
         sc.photon_atlas = static_cast<float4*>(ctx->atlas.ptr);
     }
-    // a second frame slot per lane in LDS when three workgroups per CU still fit with it (TopInLds)
+    // the BVH records of a small scene (C2: 63 records, 4 KB) go into LDS too, if need be at the price of stack entries
     sc.frame_slots_in_lds = 1;
+    if (sc.n_julias == 0 && total_bvh_records > 0 && total_bvh_records <= 128) {
+        const uint32_t entries = sc.bvh_lds_stack_entries;
+        sc.bvh_records_in_lds = static_cast<uint32_t>(total_bvh_records);
+        while (kTraceStaticLdsBytes + dynamic_lds_bytes(sc) > kLdsPerBlockFor3 && sc.bvh_lds_stack_entries > 4) sc.bvh_lds_stack_entries -= 2;
+        if (kTraceStaticLdsBytes + dynamic_lds_bytes(sc) > kLdsPerBlockFor3) {
+            sc.bvh_records_in_lds = 0;
+            sc.bvh_lds_stack_entries = entries;
+        }
+    }
+    // a second frame slot per lane in LDS when three workgroups per CU still fit with it (TopInLds)
     if (sc.n_julias == 0) {
         sc.frame_slots_in_lds = 2;
         if (kTraceStaticLdsBytes + dynamic_lds_bytes(sc) > kLdsPerBlockFor3) sc.frame_slots_in_lds = 1;
@@ -1122,6 +1135,9 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
         const size_t lds_t = dynamic_lds_bytes(sc);
         RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->trace_blocks_per_cu[0], trace_kernel<false>, 256, lds_t));
         RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->trace_blocks_per_cu[1], trace_kernel<true>, 256, lds_t));
+        if (std::getenv("RT_HIP_DEBUG_LDS") != nullptr)
+            std::fprintf(stderr, "rt_scene_upload: shade blob %u bytes (%s), BVH stack entries in LDS %u, BVH records in LDS %u, frame slots %u, dynamic LDS %zu bytes, trace_kernel blocks per CU %d\n",
+                         sc.shade_blob_bytes, sc.shade_blob_in_lds ? "in LDS" : "in HBM", sc.bvh_lds_stack_entries, sc.bvh_records_in_lds, sc.frame_slots_in_lds, lds_t, ctx->trace_blocks_per_cu[0]);
         if (sc.n_julias > 0) {
             RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->julia_blocks_per_cu[0], trace_julia_kernel<false>, kJuliaBlockThreads, 0));
             RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->julia_blocks_per_cu[1], trace_julia_kernel<true>, kJuliaBlockThreads, 0));

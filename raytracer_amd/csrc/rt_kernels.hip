@@ -244,6 +244,8 @@ struct BvhStackLds {
     unsigned* lane_base;     // this lane's column
     unsigned entries;        // 0: everything in scratch (trace_julia_kernel, whose LDS is its ray pool)
     unsigned stride;         // lanes in the workgroup
+    const DevBvhPair* nodes; // the records: sc.bvh_nodes, or the workgroup's LDS copy of a small scene's (the walk is a chain
+                             // of dependent loads: LDS answers in half the time of a vector-L1 hit)
 };
 
 template <bool STATS>
@@ -272,7 +274,7 @@ RT_DEV void query_bvh(const DevScene& sc, Lane& L, unsigned act, unsigned bvh_ro
             }
         } else {
             bump<STATS>(n, C_BVH_NODE_VISITS, 2);
-            const float4* raw = reinterpret_cast<const float4*>(sc.bvh_nodes + bvh_root + cur);
+            const float4* raw = reinterpret_cast<const float4*>(fast.nodes + bvh_root + cur);
             const float4 lo0 = raw[0], hi0 = raw[1], lo1 = raw[2], hi1 = raw[3];
             const SlabHit h0 = slab_test(lo0, hi0, L.qo, inv, L.qmax), h1 = slab_test(lo1, hi1, L.qo, inv, L.qmax);
             const unsigned c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(hi0.w);
@@ -911,8 +913,18 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(con
         table_base = lds_blob;
     }
     const ShadeTables T = tables_of(sc, table_base);
-    const BvhStackLds bvh_stack = {reinterpret_cast<unsigned*>(lds_blob + (sc.shade_blob_in_lds ? ((sc.shade_blob_bytes + 15u) & ~15u) : 0u)) + threadIdx.x,
-                                   sc.bvh_lds_stack_entries, 256u};
+    unsigned char* const lds_after_blob = lds_blob + (sc.shade_blob_in_lds ? ((sc.shade_blob_bytes + 15u) & ~15u) : 0u);
+    // dynamic LDS: [shade blob copy][BVH stack columns][second frame slot][BVH records]
+    const DevBvhPair* bvh_nodes = sc.bvh_nodes;
+    if (sc.bvh_records_in_lds != 0u) {
+        uint4* const dst = reinterpret_cast<uint4*>(lds_after_blob + sc.bvh_lds_stack_entries * 256u * sizeof(unsigned) +
+                                                    (sc.frame_slots_in_lds == 2u ? kFrameFields * 256u * sizeof(float) : 0u));
+        const uint4* const src = reinterpret_cast<const uint4*>(sc.bvh_nodes);
+        for (unsigned i = threadIdx.x; i < sc.bvh_records_in_lds * 4u; i += 256u) dst[i] = src[i];
+        __syncthreads();
+        bvh_nodes = reinterpret_cast<const DevBvhPair*>(dst);
+    }
+    const BvhStackLds bvh_stack = {reinterpret_cast<unsigned*>(lds_after_blob) + threadIdx.x, sc.bvh_lds_stack_entries, 256u, bvh_nodes};
     Counters n;
     if (STATS) for (int i = 0; i < C_COUNT; i++) n.v[i] = 0;
     const unsigned long long grid_lanes = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
@@ -1583,7 +1595,7 @@ RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob&
                 if (lane == 0) n.v[D_QUERY_PHASES]++;
                 if (q) n.v[D_QUERY_LANES]++;
             }
-            const BvhStackLds no_lds_stack = {nullptr, 0u, 0u};
+            const BvhStackLds no_lds_stack = {nullptr, 0u, 0u, sc.bvh_nodes};
             query_objects<STATS>(sc, L, q, no_lds_stack, n, ctx_hit_sink(my_ctx));
             if (q) {
                 L.state = S_RESOLVE;
@@ -1694,8 +1706,18 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
         table_base = lds_blob;
     }
     const ShadeTables T = tables_of(sc, table_base);
-    const BvhStackLds bvh_stack = {reinterpret_cast<unsigned*>(lds_blob + (sc.shade_blob_in_lds ? ((sc.shade_blob_bytes + 15u) & ~15u) : 0u)) + threadIdx.x,
-                                   sc.bvh_lds_stack_entries, 256u};
+    unsigned char* const lds_after_blob = lds_blob + (sc.shade_blob_in_lds ? ((sc.shade_blob_bytes + 15u) & ~15u) : 0u);
+    // dynamic LDS: [shade blob copy][BVH stack columns][second frame slot][BVH records]
+    const DevBvhPair* bvh_nodes = sc.bvh_nodes;
+    if (sc.bvh_records_in_lds != 0u) {
+        uint4* const dst = reinterpret_cast<uint4*>(lds_after_blob + sc.bvh_lds_stack_entries * 256u * sizeof(unsigned) +
+                                                    (sc.frame_slots_in_lds == 2u ? kFrameFields * 256u * sizeof(float) : 0u));
+        const uint4* const src = reinterpret_cast<const uint4*>(sc.bvh_nodes);
+        for (unsigned i = threadIdx.x; i < sc.bvh_records_in_lds * 4u; i += 256u) dst[i] = src[i];
+        __syncthreads();
+        bvh_nodes = reinterpret_cast<const DevBvhPair*>(dst);
+    }
+    const BvhStackLds bvh_stack = {reinterpret_cast<unsigned*>(lds_after_blob) + threadIdx.x, sc.bvh_lds_stack_entries, 256u, bvh_nodes};
     Lane L;
     L.state = S_IDLE;
     L.sp = 0;

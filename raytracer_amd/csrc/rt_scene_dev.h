@@ -151,6 +151,7 @@ struct DevScene {
     const unsigned char* shade_blob;
     uint32_t shade_blob_bytes;
     uint32_t shade_blob_in_lds;        // 0/1, decided by the host from the blob size
+    uint32_t bvh_records_in_lds;       // > 0: the scene's BVH records (all runs, this many) are few enough to be copied into LDS
     uint32_t frame_slots_in_lds;       // trace_kernel: newest frames of a lane kept in LDS, 1 or 2 (TopInLds)
     uint32_t lights_benign;            // 0/1: every light has a tame power and position (see DevMaterial::unlit)
     uint32_t bvh_lds_stack_entries;    // per-lane BVH stack entries kept in LDS (behind the blob copy); deeper ones go to scratch
