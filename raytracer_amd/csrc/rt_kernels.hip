@@ -635,6 +635,25 @@ RT_DEV void mark(Counters& n, long long& t, int slot) {
     }
 }
 
+// First light at or after `li` whose shadow ray has to be traced from an unlit surface point (resolve_lane explains);
+// kept out of line: inlined, its few live values cost the Julia kernel 70 more spilled VGPRs.
+template <bool STATS>
+__device__ __attribute__((noinline)) unsigned skip_unlit_lights(const DevLight* lights, unsigned n_lights, unsigned li, V3 point, V3 normal, bool elide, Counters& n) {
+    if (!(fabsf(point.x) + fabsf(point.y) + fabsf(point.z) < __builtin_inff() && fabsf(normal.x) + fabsf(normal.y) + fabsf(normal.z) < __builtin_inff())) return li;
+    while (li < n_lights) {
+        const DevLight& light = lights[li];
+        if (light.type != 0) {
+            const V3 d = v3(light.position[0], light.position[1], light.position[2]) - point;
+            const float dd = dot(d, d);
+            if (!(dd > 0.0f && dd < __builtin_inff())) break;
+        }
+        bump<STATS>(n, C_SHADOW_ELIDED);
+        if (!elide) break;
+        li++;
+    }
+    return li;
+}
+
 // ---- resolve phase: advance one lane's ray tree by one query result ---------------------------------
 template <bool STATS, typename Frames>
 RT_DEV void resolve_lane(const DevScene& sc, const ShadeTables& T, const DevJob& job, const Frames& frames, Lane& L, Counters& n,
@@ -741,21 +760,8 @@ RT_DEV void resolve_lane(const DevScene& sc, const ShadeTables& T, const DevJob&
         // length; then lambert, the reflected direction and pow's base are finite and pow <= e^0.25).  Such rays
         // are not traced.  A counters launch traces them (its counts are those of the reference's formulation)
         // and reports how many the plain launch skips.
-        if (L.li < sc.n_lights && sc.lights_benign != 0u && T.materials[T.object_material[L.n_obj]].unlit != 0u &&
-            fabsf(L.n_point.x) + fabsf(L.n_point.y) + fabsf(L.n_point.z) < __builtin_inff() &&
-            fabsf(L.n_normal.x) + fabsf(L.n_normal.y) + fabsf(L.n_normal.z) < __builtin_inff()) {
-            while (L.li < sc.n_lights) {
-                const DevLight& light = T.lights[L.li];
-                if (light.type != 0) {
-                    const V3 d = v3(light.position[0], light.position[1], light.position[2]) - L.n_point;
-                    const float dd = dot(d, d);
-                    if (!(dd > 0.0f && dd < __builtin_inff())) break;
-                }
-                bump<STATS>(n, C_SHADOW_ELIDED);
-                if (job.elide_unlit == 0u) break;
-                L.li++;
-            }
-        }
+        if (L.li < sc.n_lights && sc.lights_benign != 0u && T.materials[T.object_material[L.n_obj]].unlit != 0u)
+            L.li = skip_unlit_lights<STATS>(T.lights, sc.n_lights, L.li, L.n_point, L.n_normal, job.elide_unlit != 0u, n);
         if (L.li < sc.n_lights) {
             begin_shadow(T, L);
             mark<STATS>(n, t_sec, D_R_SHADOWSETUP_CYCLES);
