@@ -24,9 +24,6 @@
 namespace rtd {
 
 // register budget of the trace kernel: waves per SIMD the compiler must leave room for
-#ifndef RT_TRACE_WAVES_PER_SIMD
-#define RT_TRACE_WAVES_PER_SIMD 3   // measured on C2/C3: 3 beats 2 (occupancy) and 4 (spills)
-#endif
 #ifndef RT_PHOTON_WAVES_PER_SIMD
 #define RT_PHOTON_WAVES_PER_SIMD 3
 #endif
@@ -635,6 +632,12 @@ RT_DEV void mark(Counters& n, long long& t, int slot) {
     }
 }
 
+// pow(double, double) of the specular term (src/raytracer.cpp:233; Y8), ~250 instructions that few lit points need
+// (resolve_lane): out of line, so that its registers and its code stay out of the resolve phase's way.
+__device__ __attribute__((noinline)) float specular_pow(float base, float exponent) {
+    return static_cast<float>(pow(static_cast<double>(base), static_cast<double>(exponent)));
+}
+
 // First light at or after `li` whose shadow ray has to be traced from an unlit surface point (resolve_lane explains);
 // kept out of line: inlined, its few live values cost the Julia kernel 70 more spilled VGPRs.
 template <bool STATS>
@@ -741,7 +744,7 @@ RT_DEV void resolve_lane(const DevScene& sc, const ShadeTables& T, const DevJob&
                     }
                 }
             }
-            if (exact) spow = static_cast<float>(pow(static_cast<double>(sbase), static_cast<double>(m.exponent)));   // Y8
+            if (exact) spow = specular_pow(sbase, m.exponent);
             for (int c = 0; c < 3; c++) {
                 const float specular = light.power[c] * spow * m.ks;
                 L.acc[c] = L.acc[c] + (diffuse[c] + specular);
@@ -903,8 +906,11 @@ RT_DEV void unpark_node(const float* col, Lane& L) {
 }
 
 // ---- the render kernel (scenes without Julia sets) ----------------------------------------------------
-template <bool STATS>
-__global__ __launch_bounds__(256, RT_TRACE_WAVES_PER_SIMD) void trace_kernel(const DevScene sc_global, const DevJob job) {
+// DENSE: 4 waves per SIMD at 128 VGPRs (20 of them spilled) instead of 3 at 168 (none): the waves wait a third of their
+// time, and where a frame has the samples to fill a fourth wave per SIMD and its workgroups fit four to a CU in LDS,
+// the extra wave hides more than the spills cost (C3 10.0 -> 9.2 ms; C2 does not fit, C5 is too small: rt_api.hip).
+template <bool STATS, bool DENSE>
+__global__ __launch_bounds__(256, DENSE ? 4 : RT_TRACE_WAVES_PER_SIMD) void trace_kernel(const DevScene sc_global, const DevJob job) {
     // With a small scene the shading tables are read from an LDS copy of the shade blob (latency
     // ~64 cycles instead of an L2 round trip per dependent load); the wave-uniform geometry reads
     // keep using the HBM tables (scalar loads).
@@ -1955,8 +1961,10 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float4* __restrict_
 }
 
 // explicit instantiations used by rt_api.hip
-template __global__ void trace_kernel<false>(const DevScene, const DevJob);
-template __global__ void trace_kernel<true>(const DevScene, const DevJob);
+template __global__ void trace_kernel<false, false>(const DevScene, const DevJob);
+template __global__ void trace_kernel<true, false>(const DevScene, const DevJob);
+template __global__ void trace_kernel<false, true>(const DevScene, const DevJob);
+template __global__ void trace_kernel<true, true>(const DevScene, const DevJob);
 template __global__ void trace_julia_kernel<false>(const DevScene, const DevJob);
 template __global__ void trace_julia_kernel<true>(const DevScene, const DevJob);
 template __global__ void photon_kernel<false, false>(const DevScene, const DevPhotonJob);

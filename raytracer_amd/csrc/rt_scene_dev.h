@@ -233,6 +233,12 @@ constexpr int kJuliaMarcherWaves = RT_JULIA_MARCHERS;    // the rest are shader 
 constexpr int kJuliaPoolContexts = RT_JULIA_POOL;        // ray contexts per workgroup (LDS pool)
 constexpr uint32_t kJuliaStaticLdsBytes = 160 * 1024;    // its static LDS (pool + rings) may take the whole CU's
 
+// waves per SIMD of trace_kernel (= its 256-lane workgroups per CU): sets its register budget (168 VGPRs at 3, 128 at 4)
+// and the LDS a workgroup may take (rt_api.hip)
+#ifndef RT_TRACE_WAVES_PER_SIMD
+#define RT_TRACE_WAVES_PER_SIMD 3
+#endif
+
 enum CounterSlot : int {
     C_PRIMARY = 0, C_SECONDARY, C_SHADOW, C_PHOTON_SEGMENTS, C_PHOTON_DEPOSITS, C_SPHERE_TESTS, C_TRIANGLE_TESTS,
     C_JULIA_QUERIES, C_JULIA_STEPS, C_JULIA_DE_ITERATIONS, C_JULIA_NORMALS, C_SHADED_HITS, C_PHONG_LIGHTS,

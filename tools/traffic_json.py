@@ -34,10 +34,10 @@ def main():
         sec = sections(p)
         # the dominant kernel: the timed (STATS = false) trace kernel with the most VALU instructions; the <true>
         # instantiation is bench.py's untimed counters launch
-        names = [k for k in sec if "trace_" in k and "<false>" in k and "SQ_INSTS_VALU" in sec[k]]
+        names = [k for k in sec if "trace_" in k and ("<false>" in k or "<false," in k) and "SQ_INSTS_VALU" in sec[k]]
         k = max(names, key=lambda n: sec[n]["SQ_INSTS_VALU"])
         c = sec[k]
-        short = re.sub(r"^.*(trace_\w+<\w+>).*$", r"\1", k)
+        short = re.sub(r"^.*(trace_\w+<[\w, ]+>).*$", r"\1", k)
         gui_per_xcd = c["GRBM_GUI_ACTIVE"] / 8.0
         res[w] = {
             "kernel": short,
