@@ -510,7 +510,9 @@ RT_DEV Col texture_bilinear(const DevTexture& tex, const uint32_t* __restrict__ 
 }
 
 // ---- Fresnel (src/raytracer.cpp:243-268, again at src/photonmap.cpp:92-116) ---------------------
-RT_DEV float fresnel_kr(float refr_re, float refr_im, float dispersion, float cos_rn, float wavelength) {
+// Out of line: its double-precision complex arithmetic is a register peak of the kernels that inline everything else
+// (trace_julia_kernel spills 74 VGPRs with it out of line, 132 with it inlined).
+__device__ __attribute__((noinline)) float fresnel_kr(float refr_re, float refr_im, float dispersion, float cos_rn, float wavelength) {
     Cx etai = {1.0f, 0.0f};
     Cx etat = {refr_re + wavelength * dispersion, refr_im};
     if (cos_rn > 0.0f) {
