@@ -44,7 +44,10 @@ static size_t dynamic_lds_bytes(const rtd::DevScene& sc) {
 constexpr size_t kTraceStaticLdsBytes = (size_t(kFrameFieldsHost) + 26) * 256 * sizeof(float);   // first frame slot + parked state (rt_kernels.hip)
 constexpr size_t kLdsPerBlockFor3 = 160 * 1024 / RT_TRACE_WAVES_PER_SIMD - 512;                  // RT_TRACE_WAVES_PER_SIMD workgroups per CU
 constexpr uint64_t kDenseMinSamples = 1ull << 20;     // trace_kernel<.., DENSE> from a million samples per launch
-constexpr size_t kMaxLdsBlobBytes = 16 * 1024;   // + 11 KB of frame tops + 25 KB of parked node state: 3 blocks per CU within the 160 KB LDS
+#ifndef RT_MAX_LDS_BLOB
+#define RT_MAX_LDS_BLOB (16 * 1024)
+#endif
+constexpr size_t kMaxLdsBlobBytes = RT_MAX_LDS_BLOB;   // + 11 KB of frame tops + 25 KB of parked node state: 3 blocks per CU within the 160 KB LDS
 constexpr int kFrameRecordWordsHost = 12;       // trace_julia_kernel keeps every frame as a 48-byte record of its own
 constexpr int kJuliaBlockThreads = kJuliaWaves * 64, kJuliaShaderWavesHost = kJuliaWaves - kJuliaMarcherWaves;
 }  // namespace rtd
