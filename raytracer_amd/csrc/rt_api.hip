@@ -258,13 +258,16 @@ uint32_t static_blocks_per_wave(uint64_t items, uint64_t lanes, unsigned sixteen
     return static_cast<uint32_t>(std::min<uint64_t>(items / 64 * sixteenths / 16 / waves, 0x7fffffffull));
 }
 #ifndef RT_STATIC_SHARE_TRACE
-#define RT_STATIC_SHARE_TRACE 4
+#define RT_STATIC_SHARE_TRACE 2     // C2 (bench, 40 steps): 1.915 ms at 1, 1.878 at 2, 1.884 at 3, 1.905 at 4, 2.16 at 5
 #endif
 // with more than one sample per pixel (measured with the round-2 kernels: C3 9.21 ms at 4/16, 8.91 at 6, 8.90 at 8, 8.83 at 10,
 // 9.6 at 12; 6_supersampling 0.43 / 0.38 / 0.35 / 0.31 / 0.28; 7_dof 2.17 / 2.08 / 2.00 / 1.97 / 2.06; C2, one sample per pixel,
 // 2.04 at 4 and 2.40 at 8)
 #ifndef RT_STATIC_SHARE_TRACE_SUPERSAMPLED
 #define RT_STATIC_SHARE_TRACE_SUPERSAMPLED 10
+#endif
+#ifndef RT_STATIC_SHARE_JULIA
+#define RT_STATIC_SHARE_JULIA 4
 #endif
 #ifndef RT_STATIC_SHARE_PHOTON
 #define RT_STATIC_SHARE_PHOTON 14
@@ -349,7 +352,7 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     // a launch of at most two tiles per wave needs no counter at all (C1: 0.10 -> 0.06 ms)
     const bool tiny = job.n_samples / 64 <= 2 * (id_lanes / 64);
     job.static_blocks = tiny ? static_cast<uint32_t>((job.n_samples / 64 + id_lanes / 64 - 1) / (id_lanes / 64))
-                             : static_blocks_per_wave(job.n_samples, id_lanes, (job.samples_per_pixel > 1 && !julia) ? RT_STATIC_SHARE_TRACE_SUPERSAMPLED : RT_STATIC_SHARE_TRACE);
+                             : static_blocks_per_wave(job.n_samples, id_lanes, julia ? RT_STATIC_SHARE_JULIA : job.samples_per_pixel > 1 ? RT_STATIC_SHARE_TRACE_SUPERSAMPLED : RT_STATIC_SHARE_TRACE);
     job.dyn_base = static_cast<uint64_t>(job.n_waves) * job.static_blocks * 64ull;
     job.stack = ws.stack;
     job.queue_head = ws.queue;
