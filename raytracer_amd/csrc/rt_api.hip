@@ -30,11 +30,16 @@ __global__ void kat_fresnel_kernel(const float* in, unsigned n, float* out);
 __global__ void mul_add_kernel(float* acc, const float* src, float factor, unsigned long long n);
 __global__ void quantize_kernel(const float4* rgba, uchar4* out, float gain, unsigned long long n);
 hipError_t build_triangle_bvh(const DevTriTest* tris, uint32_t first, uint32_t n, DevBvhPair* pairs);
+void build_triangle_bvh_host(const DevTriTest* tris, uint32_t first, uint32_t n, DevBvhPair* pairs);
 hipError_t photon_order_temp_bytes(unsigned capacity, unsigned key_bits, size_t* bytes);
 hipError_t photon_order_reduce(const unsigned long long* keys, const float4* vals, unsigned capacity, unsigned key_bits, unsigned texel_shift,
                                unsigned long long n_texels, float4* atlas, unsigned long long* sorted_keys, unsigned* sorted_index,
                                unsigned* long_runs, unsigned long long* words, void* temp, size_t temp_bytes, hipStream_t stream);
 constexpr int kFrameFieldsHost = 11;
+#ifndef RT_BVH_HOST_BUILD_MAX
+#define RT_BVH_HOST_BUILD_MAX 1024
+#endif
+constexpr uint32_t kBvhHostBuildMax = RT_BVH_HOST_BUILD_MAX;   // runs up to this long get the host-built surface-area tree (rt_bvh.hip), longer ones the GPU-built Morton tree
 constexpr uint32_t kBvhLdsStackEntries = 16;   // 16 KB per workgroup of 256 lanes: with the 36 KB of frame tops and parked node state, 3 blocks per CU still fit
 // dynamic LDS of trace_kernel / photon_kernel: [copy of the shade blob, if small][BVH stack columns, if the scene has a BVH]
 static size_t dynamic_lds_bytes(const rtd::DevScene& sc) {
@@ -1111,7 +1116,13 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
             size_t at = 0;
             for (DevRun& r : runs) {
                 if (qualifies(r)) {
-                    RT_HIP_TRY(ctx, build_triangle_bvh(sc.tri_test, r.first_prim, r.count, static_cast<DevBvhPair*>(d_nodes) + at));
+                    if (r.count <= kBvhHostBuildMax) {
+                        std::vector<DevBvhPair> pairs(size_t(r.count) - 1);
+                        build_triangle_bvh_host(tt_ord.data(), r.first_prim, r.count, pairs.data());
+                        RT_HIP_TRY(ctx, hipMemcpy(static_cast<DevBvhPair*>(d_nodes) + at, pairs.data(), pairs.size() * sizeof(DevBvhPair), hipMemcpyHostToDevice));
+                    } else {
+                        RT_HIP_TRY(ctx, build_triangle_bvh(sc.tri_test, r.first_prim, r.count, static_cast<DevBvhPair*>(d_nodes) + at));
+                    }
                     r.kind = RUN_TRIANGLE_BVH;
                     r.bvh_root = static_cast<uint32_t>(at);
                     at += size_t(r.count) - 1;

@@ -15,6 +15,10 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
 #include "rt_scene_dev.h"
 
 namespace rtd {
@@ -199,6 +203,136 @@ hipError_t build_triangle_bvh(const DevTriTest* tris, uint32_t first, uint32_t n
     if ((e = hipGetLastError()) != hipSuccess) return done(e);
     e = hipDeviceSynchronize();
     return done(e);
+}
+
+// ---- host builder for short runs -------------------------------------------------------------------------------------------
+// A Morton-order tree is a poor one for a handful of large and small triangles (C2: five boxes and two planes, 64
+// triangles): a ray visited 16 records of its 63.  Runs of at most kBvhHostBuildMax triangles get a full-sweep
+// surface-area-heuristic tree built here instead — microseconds on one core, no device allocation, no launch —; any
+// tree gives the same pictures (the traversal's winner does not depend on it).  Same leaf boxes as bvh_bounds_kernel;
+// records in depth-first order (a record's first child follows it); depth bounded for the traversal's stack.
+namespace {
+
+struct HostBox {
+    float lo[3], hi[3];
+    void grow(const HostBox& o) {
+        for (int c = 0; c < 3; c++) {
+            lo[c] = std::fmin(lo[c], o.lo[c]);
+            hi[c] = std::fmax(hi[c], o.hi[c]);
+        }
+    }
+    double half_area() const {
+        const double x = double(hi[0]) - lo[0], y = double(hi[1]) - lo[1], z = double(hi[2]) - lo[2];
+        return x * y + y * z + z * x;
+    }
+};
+constexpr HostBox kEmptyBox = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+
+// The three centroid orders are sorted once; a split partitions each of them stably, so every node sweeps sorted
+// ranges without sorting again (O(n log n) in all).
+struct HostBuilder {
+    const std::vector<HostBox>& boxes;
+    uint32_t first;
+    DevBvhPair* pairs;
+    uint32_t next = 0;
+    std::vector<uint32_t> order[3], scratch;
+    std::vector<unsigned char> goes_left;
+    std::vector<double> right_area;
+
+    HostBuilder(const std::vector<HostBox>& b, uint32_t first_prim, DevBvhPair* out) : boxes(b), first(first_prim), pairs(out) {
+        const size_t n = boxes.size();
+        scratch.resize(n);
+        goes_left.resize(n);
+        right_area.resize(n);
+        for (int axis = 0; axis < 3; axis++) {
+            std::vector<uint32_t>& o = order[axis];
+            o.resize(n);
+            for (size_t i = 0; i < n; i++) o[i] = static_cast<uint32_t>(i);
+            std::sort(o.begin(), o.end(), [&](uint32_t x, uint32_t y) {
+                const float cx = boxes[x].lo[axis] + boxes[x].hi[axis], cy = boxes[y].lo[axis] + boxes[y].hi[axis];
+                return cx < cy || (!(cy < cx) && x < y);   // (NaN centroids compare as equal: ordered by index)
+            });
+        }
+    }
+
+    // Builds the subtree of the triangles in [lo, hi) of the three orders and returns its child word.
+    uint32_t build(size_t lo, size_t hi, int depth) {
+        if (hi - lo == 1) return kBvhLeafBit | (first + order[0][lo]);
+        const uint32_t me = next++;
+        const size_t n = hi - lo;
+        size_t best_at = n / 2;
+        int best_axis = 0;
+        double best_cost = INFINITY;
+        // (past the depth limit, or with no finite cost — NaN or infinite boxes —: the median of the x order)
+        for (int axis = 0; axis < 3 && depth < 32; axis++) {
+            const uint32_t* o = order[axis].data() + lo;
+            HostBox acc = kEmptyBox;
+            for (size_t i = n; i-- > 1;) {
+                acc.grow(boxes[o[i]]);
+                right_area[i] = acc.half_area();
+            }
+            acc = kEmptyBox;
+            for (size_t i = 1; i < n; i++) {
+                acc.grow(boxes[o[i - 1]]);
+                const double cost = acc.half_area() * double(i) + right_area[i] * double(n - i);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = axis;
+                    best_at = i;
+                }
+            }
+        }
+        HostBox b0 = kEmptyBox, b1 = kEmptyBox;
+        {
+            const uint32_t* o = order[best_axis].data() + lo;
+            for (size_t i = 0; i < n; i++) {
+                goes_left[o[i]] = i < best_at;
+                (i < best_at ? b0 : b1).grow(boxes[o[i]]);
+            }
+        }
+        for (int axis = 0; axis < 3; axis++) {
+            if (axis == best_axis) continue;
+            uint32_t* o = order[axis].data() + lo;
+            size_t l = 0, r = 0;
+            for (size_t i = 0; i < n; i++) {
+                if (goes_left[o[i]]) o[l++] = o[i];
+                else scratch[r++] = o[i];
+            }
+            std::copy(scratch.begin(), scratch.begin() + r, o + l);
+        }
+        const uint32_t c0 = build(lo, lo + best_at, depth + 1);
+        const uint32_t c1 = build(lo + best_at, hi, depth + 1);
+        DevBvhPair& p = pairs[me];
+        for (int c = 0; c < 3; c++) {
+            p.lo0[c] = b0.lo[c];
+            p.hi0[c] = b0.hi[c];
+            p.lo1[c] = b1.lo[c];
+            p.hi1[c] = b1.hi[c];
+        }
+        p.child0 = c0;
+        p.child1 = c1;
+        p.pad0 = p.pad1 = 0;
+        return me;
+    }
+};
+
+}  // namespace
+
+// Host counterpart of build_triangle_bvh for n <= kBvhHostBuildMax: `tris` and `pairs` are host memory.
+void build_triangle_bvh_host(const DevTriTest* tris, uint32_t first, uint32_t n, DevBvhPair* pairs) {
+    std::vector<HostBox> boxes(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const DevTriTest& t = tris[first + i];
+        for (int c = 0; c < 3; c++) {
+            const float p0 = t.p0[c], p1 = t.p0[c] + t.e1[c], p2 = t.p0[c] + t.e2[c];
+            const float lo = std::fmin(p0, std::fmin(p1, p2)), hi = std::fmax(p0, std::fmax(p1, p2));
+            const float grow = 2.0f * 0.0001f * (std::fabs(t.e1[c]) + std::fabs(t.e2[c])) + 4e-6f * std::fmax(std::fabs(lo), std::fabs(hi)) + 1e-30f;
+            boxes[i].lo[c] = lo - grow;
+            boxes[i].hi[c] = hi + grow;
+        }
+    }
+    HostBuilder b(boxes, first, pairs);
+    (void)b.build(0, n, 0);
 }
 
 }  // namespace rtd
