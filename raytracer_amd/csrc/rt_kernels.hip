@@ -35,6 +35,9 @@ namespace rtd {
 #ifndef RT_JULIA_SHADER_PRIO
 #define RT_JULIA_SHADER_PRIO 0
 #endif
+#ifndef RT_JULIA_TAIL_RING
+#define RT_JULIA_TAIL_RING 1
+#endif
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 64
 #endif
@@ -1108,17 +1111,20 @@ enum CtxWord : int {
 };
 enum CtxFlag : unsigned { CF_KIND_MASK = 3u, CF_QACTIVE = 4u, CF_BLOCKED = 8u, CF_FOUND = 16u, CF_WAITING = 32u, CF_FRESH = 64u };
 enum JobStatus : unsigned { JOB_PENDING = 0u, JOB_MISS = 1u, JOB_HIT = 2u };
-enum RingId : int { R_MARCH = 0, R_NORMAL = 1, R_READY_T = 2, R_READY_S = 3, R_COUNT = 4 };
+enum RingId : int { R_MARCH = 0, R_NORMAL = 1, R_READY_T = 2, R_READY_S = 3, R_TAIL = 4, R_COUNT = 5 };
 
-// Entry i of a ring lives at slot[i & (cap-1)] as ring_word(i, context id): one store publishes both.
+// Entry i of a ring lives at slot[i & (cap-1)] as ring_word(i, context id): one 16-bit store publishes the id and the
+// lap it belongs to (a slot holds the previous lap's word until its producer has written, so the lap number tells a
+// consumer that came first to wait; 16-bit words: five rings of 1024 entries and 896 contexts fill the CU's 160 KB).
 struct JuliaRing {
-    unsigned slot[kJuliaQueueCap];
+    unsigned short slot[kJuliaQueueCap];
 };
-RT_DEV unsigned ring_word(unsigned i, unsigned id) { return (0x80000000u | ((i & 0x7fffu) << 16)) | id; }
-RT_DEV bool ring_word_is(unsigned v, unsigned i) { return (v >> 16) == (0x8000u | (i & 0x7fffu)); }
+static_assert(kJuliaQueueCap == 1024u, "ring_word packs a 10-bit context id under a 5-bit lap number");
+RT_DEV unsigned short ring_word(unsigned i, unsigned id) { return static_cast<unsigned short>(0x8000u | (((i >> 10) & 31u) << 10) | id); }
+RT_DEV bool ring_word_is(unsigned v, unsigned i) { return (v >> 10) == (32u | ((i >> 10) & 31u)); }
 struct PoolShared {
     // running counts (never wrapped) of the rings: entries head..tail-1 of ring r are reserved, ctl[2r] = head, ctl[2r+1] = tail
-    __attribute__((aligned(16))) unsigned ctl[2 * R_COUNT];
+    __attribute__((aligned(16))) unsigned ctl[12];
     unsigned dead;          // contexts that found the sample queue empty
     unsigned abort;
     unsigned heartbeat;     // bumped by every wave that made progress (watchdog)
@@ -1128,9 +1134,12 @@ struct PoolShared {
     __attribute__((aligned(16))) float ctx[kPoolCtx][kCtxWords];
 };
 static_assert(sizeof(PoolShared) <= kJuliaStaticLdsBytes, "kJuliaStaticLdsBytes");
+static_assert(2 * R_COUNT <= 12, "ctl");
 
 RT_DEV unsigned lds_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 RT_DEV void lds_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+RT_DEV unsigned lds_load(const unsigned short* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+RT_DEV void lds_store(unsigned short* p, unsigned short v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 RT_DEV void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 RT_DEV void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
@@ -1173,7 +1182,7 @@ RT_DEV unsigned ring_pop(unsigned* head_word, const unsigned* tail_word, unsigne
 }
 // Context id of reserved entry i (waits for the producer's write; bounded by the 100 MHz clock).
 RT_DEV unsigned ring_entry(JuliaRing& q, unsigned i, unsigned* abort_flag) {
-    const unsigned* w = &q.slot[i & (kJuliaQueueCap - 1)];
+    const unsigned short* w = &q.slot[i & (kJuliaQueueCap - 1)];
     unsigned v = lds_load(w);
     if (!ring_word_is(v, i)) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -1185,7 +1194,7 @@ RT_DEV unsigned ring_entry(JuliaRing& q, unsigned i, unsigned* abort_flag) {
         }
     }
     lds_acquire();
-    return v & 0xffffu;
+    return v & 0x3ffu;
 }
 
 // A wave that has nothing to do sleeps and watches the workgroup's heartbeat: the launch is given up only when no
@@ -1488,6 +1497,200 @@ RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n) {
     }
 }
 
+// ---- marcher waves, march steps pooled through the TAIL ring (RT_JULIA_TAIL_RING) -----------------------------------
+// julia_marcher above takes the march steps of its own lanes, so a lane whose estimate is complete idles until enough
+// of its wave's lanes are (measured on C4: 37 of 64 lanes per step phase, a third of the estimator's lane slots
+// empty).  Here a marcher lane owns nothing but an estimate: a finished one leaves (m2, d2) in its context and the
+// context on the TAIL ring, and the lane takes the next job at once; any marcher wave that sees 64 entries on TAIL
+// takes their march steps at full width and sends each context back to MARCH (the position advanced, the step count
+// in the flags word), on to NORMAL (converged) or to a READY ring (missed).
+constexpr int CW_D2 = CW_UNION + 19;       // free in both uses of the union words
+constexpr unsigned kStepShift = 8u;        // march step index in the flags word above the CtxFlag bits
+#ifndef RT_JULIA_RETIRE_EIGHTHS
+#define RT_JULIA_RETIRE_EIGHTHS 2          // finished estimates are retired once this many eighths of a wave's lanes hold one
+#endif
+template <bool STATS>
+RT_DEV void julia_marcher_pooled(const DevScene& sc, PoolShared& sh, Counters& n) {
+    const int lane = threadIdx.x & 63;
+    bool has = false, busy = false;
+    unsigned owner = 0, it = 0;
+    JuliaPk s = julia_pk_begin({0, 0, 0, 0});
+    PkF2 cp = {0, 0}, cq = {0, 0};
+    IdleWatch watch = {0u, 0ull, false};
+    long long t_mark = STATS ? clock64() : 0;
+    auto charge = [&](int slot) {
+        if (STATS) {
+            const long long now = clock64();
+            if (lane == 0) n.v[slot] += static_cast<unsigned long long>(now - t_mark);
+            t_mark = now;
+        }
+    };
+    for (;;) {
+        typedef unsigned U4 __attribute__((ext_vector_type(4)));
+        const U4 ctl = *reinterpret_cast<volatile U4*>(sh.ctl);                  // march head, tail, normal head, tail
+        const U4 ctl_t = *reinterpret_cast<volatile U4*>(sh.ctl + 2 * R_TAIL);   // tail head, tail
+        const U4 flags = *reinterpret_cast<volatile U4*>(&sh.dead);              // dead, abort, heartbeat
+        if (flags.y != 0u) break;
+        const int n_has0 = __popcll(__ballot(has));
+        const unsigned n_conv = ctl.w - ctl.z, n_jobs = ctl.y - ctl.x, n_tail = ctl_t.y - ctl_t.x;
+        if (STATS && lane == 0) {
+            n.v[D_MARCH_POLLS]++;
+            n.v[D_MARCH_HAS_SUM] += static_cast<unsigned long long>(n_has0);
+        }
+        // ---- finish converged jobs: a full batch at once, a partial one when there is little else to do
+        if (n_conv >= 64u || (n_conv > 0u && n_has0 < RT_JULIA_NORMAL_IDLE && n_jobs == 0u && n_tail == 0u)) {
+            unsigned first = 0;
+            const unsigned got = ring_pop(&sh.ctl[2 * R_NORMAL], &sh.ctl[2 * R_NORMAL + 1], 64u, first);
+            bool to_t = false, to_s = false;
+            unsigned o = 0;
+            if (static_cast<unsigned>(lane) < got) {
+                o = ring_entry(sh.ring[R_NORMAL], first + lane, &sh.abort);
+                float* c = sh.ctx[o];
+                const F4 q0 = ctx_get(c, CW_QO), q1 = ctx_get(c, CW_QD), j0 = ctx_get(c, CW_JP), j1 = ctx_get(c, CW_JD);
+                const DevJulia& j = sc.julias[__float_as_uint(c[CW_JIDX])];
+                bump<STATS>(n, C_JULIA_NORMALS);
+                unsigned long long iters = 0;
+                HitRec h;
+                // the distance limits of src/objects.cpp:236 are applied by the shader wave (it knows the query)
+                const bool hit = julia_finish<STATS>(j, v3(q0.x, q0.y, q0.z), v3(j0.x, j0.y, j0.z), v3(j1.x, j1.y, j1.z), kInfinite, h, iters);
+                bump<STATS>(n, C_JULIA_DE_ITERATIONS, iters);
+                if (hit) {
+                    ctx_put(c, CW_JP, F4{h.point.x, h.point.y, h.point.z, h.dist});
+                    ctx_put(c, CW_JD, F4{h.normal.x, h.normal.y, h.normal.z, __uint_as_float(JOB_HIT)});
+                } else {
+                    c[CW_JSTATUS] = __uint_as_float(JOB_MISS);
+                }
+                const bool shadow = (__float_as_uint(q1.w) & CF_KIND_MASK) == static_cast<unsigned>(Q_SHADOW);
+                to_s = shadow;
+                to_t = !shadow;
+            }
+            ring_push(sh.ring[R_READY_T], &sh.ctl[2 * R_READY_T + 1], to_t, o);
+            ring_push(sh.ring[R_READY_S], &sh.ctl[2 * R_READY_S + 1], to_s, o);
+            beat(sh);
+            if (STATS && lane == 0) n.v[D_NORMAL_PHASES]++;
+            if (STATS && static_cast<unsigned>(lane) < got) n.v[D_NORMAL_LANES]++;
+            charge(D_NORMAL_CYCLES);
+            continue;
+        }
+        // ---- march steps (src/objects.cpp:206-221) of a full batch of complete estimates; of a partial one when the
+        // MARCH ring is empty and this wave has room (whatever is on TAIL is then what the idle lanes wait for)
+        if (n_tail >= 64u || (n_tail > 0u && n_jobs == 0u && n_has0 <= 48)) {
+            unsigned first = 0;
+            const unsigned got = ring_pop(&sh.ctl[2 * R_TAIL], &sh.ctl[2 * R_TAIL + 1], 64u, first);
+            bool again = false, converged = false, miss_t = false, miss_s = false;
+            unsigned o = 0;
+            if (static_cast<unsigned>(lane) < got) {
+                o = ring_entry(sh.ring[R_TAIL], first + lane, &sh.abort);
+                float* c = sh.ctx[o];
+                const F4 j0 = ctx_get(c, CW_JP), j1 = ctx_get(c, CW_JD);      // position and m2; direction and status
+                const float d2 = c[CW_D2];
+                const unsigned fl = __float_as_uint(c[CW_FLAGS]);
+                unsigned jstep = fl >> kStepShift;
+                V3 p = v3(j0.x, j0.y, j0.z);
+                bump<STATS>(n, C_JULIA_STEPS);
+                const int r = julia_advance(julia_distance_tail_march(j0.w, d2), p, v3(j1.x, j1.y, j1.z), jstep);
+                if (r == 2) {
+                    c[CW_JSTATUS] = __uint_as_float(JOB_MISS);
+                    miss_s = (fl & CF_KIND_MASK) == static_cast<unsigned>(Q_SHADOW);
+                    miss_t = !miss_s;
+                } else {
+                    c[CW_JP] = p.x;
+                    c[CW_JP + 1] = p.y;
+                    c[CW_JP + 2] = p.z;
+                    if (r == 0) c[CW_FLAGS] = __uint_as_float((fl & ((1u << kStepShift) - 1u)) | (jstep << kStepShift));
+                    again = r == 0;
+                    converged = r == 1;
+                }
+            }
+            ring_push(sh.ring[R_MARCH], &sh.ctl[2 * R_MARCH + 1], again, o);
+            ring_push(sh.ring[R_NORMAL], &sh.ctl[2 * R_NORMAL + 1], converged, o);
+            ring_push(sh.ring[R_READY_T], &sh.ctl[2 * R_READY_T + 1], miss_t, o);
+            ring_push(sh.ring[R_READY_S], &sh.ctl[2 * R_READY_S + 1], miss_s, o);
+            beat(sh);
+            if (STATS && lane == 0) n.v[D_M_TAIL_BLOCKS]++;
+            if (STATS && static_cast<unsigned>(lane) < got) n.v[D_M_TAIL_LANES]++;
+            charge(D_M_TAIL_CYCLES);
+            continue;
+        }
+        // ---- refill idle lanes from the march ring
+        const unsigned long long need = __ballot(!has);
+        if (need != 0ull && n_jobs != 0u) {
+            unsigned first = 0;
+            const unsigned got = ring_pop(&sh.ctl[2 * R_MARCH], &sh.ctl[2 * R_MARCH + 1], static_cast<unsigned>(__popcll(need)), first);
+            const unsigned rank = __popcll(need & ((1ull << lane) - 1ull));
+            if (!has && rank < got) {
+                owner = ring_entry(sh.ring[R_MARCH], first + rank, &sh.abort);
+                const float* c = sh.ctx[owner];
+                const F4 j0 = ctx_get(c, CW_JP);
+                const unsigned jidx = __float_as_uint(c[CW_JIDX]);
+                float cut;
+                if (jidx < static_cast<unsigned>(kJuliaConstTable)) {
+                    const F4 c4 = *reinterpret_cast<const F4*>(sh.jconst[jidx]);
+                    cp = {c4.x, c4.y};
+                    cq = {c4.z, c4.w};
+                    cut = sh.jconst[jidx][4];
+                } else {
+                    const DevJulia& j = sc.julias[jidx];
+                    cp = {j.c[0], j.c[1]};
+                    cq = {j.c[2], j.c[3]};
+                    cut = j.cut_plane;
+                }
+                s = julia_pk_begin({j0.x, j0.y, j0.z, cut});
+                it = 0;
+                has = true;
+                busy = true;
+            }
+        }
+        const int n_has = __popcll(__ballot(has));
+        if (n_has == 0) {
+            if (flags.x >= static_cast<unsigned>(kPoolCtx)) break;     // every context is dead: no job can come any more
+            idle_wait(sh, watch);
+            charge(D_M_IDLE_CYCLES);
+            continue;
+        }
+        watch.armed = false;
+        charge(D_M_REFILL_CYCLES);
+        if (STATS && lane == 0) n.v[D_MARCH_PHASES]++;
+        if (STATS && has) n.v[D_MARCH_LANES]++;
+        // ---- estimator iterations, four at a time, until enough lanes hold a complete estimate (or, with lanes to
+        // spare, for four blocks: new jobs may have come)
+        for (int blocks = 1;; blocks++) {
+            if (busy) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    bump<STATS>(n, C_JULIA_DE_ITERATIONS);
+                    julia_pk_iterate_only(s, cp, cq);
+                    // (the counters build stops where the oracle's count stops: at the overflow of d2 itself)
+                    if (s.m2 > 1e10f || (STATS && s.d2 == __builtin_inff())) break;
+                }
+                it++;   // blocks of four
+                // exact early-out once d2 has overflowed, looked at once per block: further iterations
+                // cannot change the value the march uses
+                if (s.m2 > 1e10f || s.d2 == __builtin_inff() || it >= kJuliaDistanceIterations / 4) busy = false;
+            }
+            if (STATS && lane == 0) n.v[D_DE_WAVE_ITERS] += 256ull;
+            const int n_busy = __popcll(__ballot(busy));
+            if (n_busy == 0 || (n_has - n_busy) * 8 >= 64 * RT_JULIA_RETIRE_EIGHTHS || (n_has < 56 && blocks >= 4)) break;
+        }
+        charge(D_MARCH_CYCLES);
+        // ---- retire the complete estimates
+        const bool retire = has && !busy;
+        if (retire) {
+            float* c = sh.ctx[owner];
+            c[CW_JDIST] = s.m2;
+            c[CW_D2] = s.d2;
+            has = false;
+            if (STATS) {
+                const int b = it <= 1u ? 0 : it <= 2u ? 1 : it <= 4u ? 2 : it <= 8u ? 3 : it <= 16u ? 4 : it <= 32u ? 5 : 6;
+                n.v[D_STEP_BLOCKS_1 + b]++;
+                n.v[D_STEP_BLOCK_SUM] += it;
+            }
+        }
+        ring_push(sh.ring[R_TAIL], &sh.ctl[2 * R_TAIL + 1], retire, owner);
+        beat(sh);
+    }
+}
+
 // ---- shader waves -------------------------------------------------------------------------------------------
 template <bool STATS>
 RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob& job, PoolShared& sh, Counters& n, WaveIds& wave_ids) {
@@ -1656,7 +1859,7 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
         }
     }
     if (threadIdx.x == 0) {
-        for (int w = 0; w < 2 * R_COUNT; w++) sh.ctl[w] = 0u;
+        for (int w = 0; w < 12; w++) sh.ctl[w] = 0u;
         sh.ctl[2 * R_READY_T + 1] = static_cast<unsigned>(kPoolCtx);
         sh.dead = 0u;
         sh.abort = (job.debug_abort != 0u && blockIdx.x == 0) ? 1u : 0u;   // RT_OPT_DEBUG_FORCE_ABORT
@@ -1669,7 +1872,11 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
     if (STATS) for (int i = 0; i < C_COUNT; i++) n.v[i] = 0;
     const int wave = threadIdx.x >> 6;
     if (wave < kJuliaMarcherWaves) {
+#if RT_JULIA_TAIL_RING
+        julia_marcher_pooled<STATS>(sc, sh, n);
+#else
         julia_marcher<STATS>(sc, sh, n);
+#endif
     } else {
         const unsigned shader_wave = blockIdx.x * (kJuliaWaves - kJuliaMarcherWaves) + (wave - kJuliaMarcherWaves);
         WaveIds wave_ids = wave_ids_begin(static_cast<unsigned long long>(shader_wave) << 6, job.n_waves, job.static_blocks);
