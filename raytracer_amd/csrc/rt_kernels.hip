@@ -36,7 +36,7 @@ namespace rtd {
 #define RT_JULIA_SHADER_PRIO 0
 #endif
 #ifndef RT_JULIA_TAIL_RING
-#define RT_JULIA_TAIL_RING 1
+#define RT_JULIA_TAIL_RING 0
 #endif
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 64
@@ -1506,6 +1506,9 @@ RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n) {
 // in the flags word), on to NORMAL (converged) or to a READY ring (missed).
 constexpr int CW_D2 = CW_UNION + 19;       // free in both uses of the union words
 constexpr unsigned kStepShift = 8u;        // march step index in the flags word above the CtxFlag bits
+#ifndef RT_JULIA_PARTIAL_TAIL_HAS
+#define RT_JULIA_PARTIAL_TAIL_HAS 48      // a partial batch of march steps is taken by a wave with at most this many estimates in hand, when MARCH is empty
+#endif
 #ifndef RT_JULIA_RETIRE_EIGHTHS
 #define RT_JULIA_RETIRE_EIGHTHS 2          // finished estimates are retired once this many eighths of a wave's lanes hold one
 #endif
@@ -1574,7 +1577,7 @@ RT_DEV void julia_marcher_pooled(const DevScene& sc, PoolShared& sh, Counters& n
         }
         // ---- march steps (src/objects.cpp:206-221) of a full batch of complete estimates; of a partial one when the
         // MARCH ring is empty and this wave has room (whatever is on TAIL is then what the idle lanes wait for)
-        if (n_tail >= 64u || (n_tail > 0u && n_jobs == 0u && n_has0 <= 48)) {
+        if (n_tail >= 64u || (n_tail > 0u && n_jobs == 0u && n_has0 <= RT_JULIA_PARTIAL_TAIL_HAS)) {
             unsigned first = 0;
             const unsigned got = ring_pop(&sh.ctl[2 * R_TAIL], &sh.ctl[2 * R_TAIL + 1], 64u, first);
             bool again = false, converged = false, miss_t = false, miss_s = false;
