@@ -512,7 +512,36 @@ RT_DEV Col texture_bilinear(const DevTexture& tex, const uint32_t* __restrict__ 
 // ---- Fresnel (src/raytracer.cpp:243-268, again at src/photonmap.cpp:92-116) ---------------------
 // Out of line: its double-precision complex arithmetic is a register peak of the kernels that inline everything else
 // (trace_julia_kernel spills 74 VGPRs with it out of line, 132 with it inlined).
+//
+// A REAL index (no extinction coefficient: the scene format's default, C2's glass) makes every imaginary part of the
+// computation a zero of one sign or the other, and the real parts those of real arithmetic: __divsc3's
+// (a*c + b*d)/(c*c + d*d) in double becomes (a*c)/(c*c) with both products exact, a correctly rounded double of
+// the real number a/c, whose rounding to float is the float quotient itself (53 >= 2*24 + 2 bits: double rounding
+// is innocuous); csqrtf takes its im == 0, re > 0 branch (1 - S*S >= 2^-24 when S*S < 1); products with a zero
+// imaginary part add or subtract a zero from a non-zero real part; std::norm adds +0.  So for a finite positive
+// index the whole term is float arithmetic, bit for bit (test_fresnel_of_real_indices_against_the_oracle); anything
+// else (a complex, non-positive, huge or NaN index, a NaN cosine) takes the complex route below.
 __device__ __attribute__((noinline)) float fresnel_kr(float refr_re, float refr_im, float dispersion, float cos_rn, float wavelength) {
+    {
+        const float index = refr_re + wavelength * dispersion;
+        if (refr_im == 0.0f && index >= 1e-3f && index <= 1e3f && fabsf(cos_rn) <= 1.0f) {
+            const bool inside = cos_rn > 0.0f;
+            const float ei = inside ? index : 1.0f, et = inside ? 1.0f : index;
+            const float one_minus = 1 - cos_rn * cos_rn;
+            const float sin_i = sqrtf(0.0f < one_minus ? one_minus : 0.0f);
+            const float st = (ei / et) * sin_i;
+            const float st2 = st * st;
+            if (st2 < 1.0f) {
+                const float ct = sqrtf(-st2 + 1.0f);
+                const float ca = fabsf(cos_rn);
+                const float tc = et * ca, ic = ei * ca, i_ct = ei * ct, t_ct = et * ct;
+                const float rs = (tc - i_ct) / (tc + i_ct);
+                const float rp = (ic - t_ct) / (ic + t_ct);
+                return (rs * rs + rp * rp) / 2;
+            }
+            return 1.0f;
+        }
+    }
     Cx etai = {1.0f, 0.0f};
     Cx etat = {refr_re + wavelength * dispersion, refr_im};
     if (cos_rn > 0.0f) {

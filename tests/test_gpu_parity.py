@@ -78,6 +78,34 @@ def test_intersectors_against_reference_answers(hip_ctx, name, rel):
         assert np.array_equal(kr.view(np.uint32), fres[:, 3])
 
 
+def test_fresnel_of_real_indices_against_the_oracle(hip_ctx):
+    # fresnel_kr's float route for real refraction indices (rt_intersect.h) against std::complex<float> as the oracle's
+    # compiler and libraries evaluate it (src/raytracer.cpp:243-268): indices from 0.001 to 1000 and just outside,
+    # both signs of a zero extinction coefficient, every cosine incl. 0, +-1 and the total-reflection boundary
+    rng = np.random.default_rng(77)
+    n = 60000
+    rec5 = np.zeros((n, 5), dtype=np.float32)
+    rec5[:, 0] = np.exp(rng.uniform(np.log(5e-4), np.log(2e3), size=n))
+    rec5[: n // 2, 0] = rng.uniform(1.0, 2.5, size=n // 2)
+    rec5[:, 1] = np.where(rng.uniform(size=n) < 0.5, 0.0, -0.0)
+    rec5[:, 2] = np.where(rng.uniform(size=n) < 0.5, 0.0, rng.uniform(-0.3, 0.3, size=n))
+    rec5[:, 3] = rng.uniform(-1, 1, size=n)
+    rec5[:200, 3] = np.repeat(np.float32([0.0, -0.0, 1.0, -1.0]), 50)
+    crit = np.sqrt(np.maximum(0.0, 1.0 - 1.0 / rec5[200:1200, 0].astype(np.float64) ** 2))     # sin_t = 1 from inside
+    rec5[200:1200, 3] = np.nextafter(crit.astype(np.float32), rng.choice([0.0, 1.0], size=1000).astype(np.float32))
+    rec5[:, 4] = rng.uniform(-1, 1, size=n)
+    kr = np.zeros(n, dtype=np.float32)
+    assert capi.hip_lib().rt_kat_fresnel(hip_ctx._ctx, rec5.ctypes.data_as(C.POINTER(C.c_float)), n, kr.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    m = capi.Material()
+    want = np.zeros(n, dtype=np.float32)
+    for i in range(n):
+        m.refraction_re, m.refraction_im, m.dispersion = float(rec5[i, 0]), float(rec5[i, 1]), float(rec5[i, 2])
+        want[i] = oracle_lib.fresnel(m, float(rec5[i, 3]), float(rec5[i, 4]))
+    bad = np.nonzero(kr.view(np.uint32) != want.view(np.uint32))[0]
+    assert len(bad) == 0, (len(bad), rec5[bad[:5]], kr[bad[:5]], want[bad[:5]])
+    assert 0.2 < np.mean(kr == 1.0) < 0.8 or np.mean(kr < 1.0) > 0.3
+
+
 def test_intersectors_on_seeded_rays_against_oracle(hip_ctx):
     # more rays than the committed fixtures hold, incl. degenerate ones (a == 0 in Möller–Trumbore:
     # axis-parallel rays against axis-aligned walls)
