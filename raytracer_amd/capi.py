@@ -20,6 +20,7 @@ RT_HUE_INT_ABS, RT_HUE_FLOAT_ABS = 0, 1
 RT_OPT_COLLECT_STATS, RT_OPT_BVH_MIN_TRIANGLES, RT_OPT_DOF_SEED, RT_OPT_PHOTON_ORDER, RT_OPT_PHOTON_RECORDS = 1, 2, 3, 4, 5
 RT_OPT_DEBUG_FORCE_ABORT = 6
 RT_OPT_ELIDE_UNLIT_SHADOWS = 7
+RT_OPT_CULL_PHOTON_ROOTS = 8
 RT_DEFAULT_BVH_MIN_TRIANGLES = 48
 FLT_MAX = float(np.finfo(np.float32).max)
 
@@ -90,7 +91,7 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "primary_rays", "secondary_rays", "shadow_rays", "photon_segments", "photon_deposits", "sphere_tests",
         "triangle_tests", "julia_queries", "julia_steps", "julia_de_iterations", "julia_normals", "shaded_hits",
-        "phong_lights", "fresnel_evals", "texture_lookups", "bvh_node_visits")] + [("kernel_ms", C.c_double), ("shadow_rays_elided", C.c_uint64)]
+        "phong_lights", "fresnel_evals", "texture_lookups", "bvh_node_visits")] + [("kernel_ms", C.c_double), ("shadow_rays_elided", C.c_uint64), ("photon_roots_culled", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

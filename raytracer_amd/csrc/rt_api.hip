@@ -24,6 +24,7 @@ template <bool STATS>
 __global__ void trace_julia_kernel(const DevScene sc, const DevJob job);
 template <bool HAS_JULIA, bool STATS>
 __global__ void photon_kernel(const DevScene sc, const DevPhotonJob job);
+__global__ void photon_cull_kernel(const DevScene sc, const DevPhotonJob job, unsigned n_dirs, uint32_t* live_dirs, unsigned long long* live_count);
 __global__ void sum_samples_kernel(const float4* samples, float4* out, unsigned long long n_pixels, unsigned samples_per_pixel, float inv_samples);
 __global__ void kat_intersect_kernel(const DevScene sc, const unsigned* kind, const unsigned* prim, const float* rays, unsigned n, float* out);
 __global__ void kat_fresnel_kernel(const float* in, unsigned n, float* out);
@@ -125,9 +126,10 @@ struct rt_ctx {
     bool photon_order = true;          // RT_OPT_PHOTON_ORDER: deposits summed in the reference's order
     // ordered photon deposits (rt_photon_order.hip)
     Buffer dep_keys, dep_vals, dep_sorted_keys, dep_sorted_index, dep_long_runs, dep_temp;
+    Buffer live_dirs;                            // RT_OPT_CULL_PHOTON_ROOTS: the directions of the photon pass that may meet a specular object
     uint32_t dep_capacity = 0;         // records; 0 = choose from the number of roots
     size_t dep_temp_bytes = 0;
-    unsigned long long* d_dep_words = nullptr;   // [0] records reserved, [1] deposits that found the buffer full, [2] long runs, [3] deposits beyond a root's key field
+    unsigned long long* d_dep_words = nullptr;   // [0] records reserved, [1] deposits that found the buffer full, [2] long runs, [3] deposits beyond a root's key field, [4] live directions (photon_cull_kernel)
     unsigned long long* h_dep_words = nullptr;   // pinned copy, written by the stream after every ordered pass
     hipEvent_t ev_dep = nullptr;
     bool dep_check_pending = false;
@@ -143,6 +145,7 @@ struct rt_ctx {
     bool status_pending = false;                // a render launch whose watchdog word has not been looked at yet
     bool debug_force_abort = false;             // RT_OPT_DEBUG_FORCE_ABORT
     bool elide_unlit_shadows = true;            // RT_OPT_ELIDE_UNLIT_SHADOWS
+    bool cull_photon_roots = true;              // RT_OPT_CULL_PHOTON_ROOTS
     unsigned long long* status_flag = nullptr;  // device word the pending status was copied from (cleared once seen)
     unsigned char* noalloc_scratch = nullptr;   // address of `scratch` on this context's device (hipGetSymbolAddress)
     // persistent grid of the render kernels for the uploaded scene ([0] plain, [1] counters build): asked once per upload
@@ -524,6 +527,20 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
             RT_HIP_TRY(ctx, hipMemsetAsync(ctx->dep_keys.ptr, 0xFF, static_cast<size_t>(ctx->dep_capacity) * sizeof(unsigned long long), stream));
             RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_dep_words, 0, 4 * sizeof(unsigned long long), stream));
         }
+        // roots that can leave nothing are dropped before the pass (DevScene::photon_cull_*; not for a slice of the pass,
+        // and not under counters: that launch traces every root and checks the claim)
+        job.static_sixteenths = RT_STATIC_SHARE_PHOTON;
+        const uint64_t n_dirs = static_cast<uint64_t>(job.n_point_lights) * job.n_phi * job.n_theta;
+        if (ctx->cull_photon_roots && !stats && n_parts == 1 && ctx->dev.photon_cull_valid != 0u && all_roots < (1ull << 32)) {
+            if (ctx->live_dirs.bytes < n_dirs * sizeof(uint32_t)) RT_HIP_TRY(ctx, hipDeviceSynchronize());
+            if ((rc = grow(ctx, ctx->live_dirs, n_dirs * sizeof(uint32_t))) != RT_OK) return rc;
+            RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_dep_words + 4, 0, sizeof(unsigned long long), stream));
+            hipLaunchKernelGGL(photon_cull_kernel, dim3(static_cast<unsigned>((n_dirs + 255) / 256)), dim3(256), 0, stream, ctx->dev, job,
+                               static_cast<unsigned>(n_dirs), static_cast<uint32_t*>(ctx->live_dirs.ptr), ctx->d_dep_words + 4);
+            RT_HIP_TRY(ctx, hipGetLastError());
+            job.live_dirs = static_cast<const uint32_t*>(ctx->live_dirs.ptr);
+            job.live_count = ctx->d_dep_words + 4;
+        }
         if (julia) {
             if (stats) hipLaunchKernelGGL((photon_kernel<true, true>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
             else hipLaunchKernelGGL((photon_kernel<true, false>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
@@ -570,6 +587,7 @@ int read_stats(rt_ctx* ctx, rt_stats* out) {
     out->texture_lookups = c[C_TEXTURE_LOOKUPS];
     out->bvh_node_visits = c[C_BVH_NODE_VISITS];
     out->shadow_rays_elided = c[C_SHADOW_ELIDED];
+    out->photon_roots_culled = c[C_PHOTON_ROOTS_CULLED];
     if (ctx->events_pending) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) == hipSuccess) out->kernel_ms = ms;
@@ -684,7 +702,7 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
     ctx->n_cus = prop.multiProcessorCount;
     if (hipMalloc(reinterpret_cast<void**>(&ctx->d_queue), 256) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), C_COUNT * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&ctx->d_dep_words), 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&ctx->d_dep_words), 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->h_dep_words), 4 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&ctx->ev_dep) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess ||
@@ -719,7 +737,7 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
     for (Buffer* b : {&ctx->scene_arena, &ctx->bvh_nodes, &ctx->atlas, &ctx->out8, &ctx->acc, &ctx->samples, &ctx->stack, &ctx->out_staging, &ctx->kat_a, &ctx->kat_b, &ctx->kat_c, &ctx->kat_d,
-                      &ctx->dep_keys, &ctx->dep_vals, &ctx->dep_sorted_keys, &ctx->dep_sorted_index, &ctx->dep_long_runs, &ctx->dep_temp}) {
+                      &ctx->dep_keys, &ctx->dep_vals, &ctx->dep_sorted_keys, &ctx->dep_sorted_index, &ctx->dep_long_runs, &ctx->dep_temp, &ctx->live_dirs}) {
         if (b->ptr) (void)hipFree(b->ptr);
     }
     if (ctx->d_dep_words) (void)hipFree(ctx->d_dep_words);
@@ -746,6 +764,7 @@ int rt_set_option(rt_ctx* ctx, int option, int64_t value) {
             return RT_OK;
         case RT_OPT_DEBUG_FORCE_ABORT: ctx->debug_force_abort = value != 0; return RT_OK;
         case RT_OPT_ELIDE_UNLIT_SHADOWS: ctx->elide_unlit_shadows = value != 0; return RT_OK;
+        case RT_OPT_CULL_PHOTON_ROOTS: ctx->cull_photon_roots = value != 0; return RT_OK;
         default: return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
     }
 }
@@ -1049,6 +1068,47 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
             b.pad = 0.0f;
         }
         if ((rc = upload(ctx, sb, &sc.sphere_bounds)) != RT_OK) return rc;
+        // DevScene::photon_cull_*: the box no photon root can do anything outside of
+        bool valid = true, any = false;
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        double oo_max = 0.0;      // |origin|^2 of a root: the lights' positions (the sphere slack grows with it)
+        for (const DevLight& l : lights) oo_max = std::fmax(oo_max, double(l.position[0]) * l.position[0] + double(l.position[1]) * l.position[1] + double(l.position[2]) * l.position[2]);
+        auto specular = [&](uint32_t object) { return !(mats[obj_material[object]].refr_norm <= 0.0f); };   // as photon_kernel decides it
+        for (const DevJulia& j : julias) {
+            if (!(mats[j.material].refr_norm <= 0.0f)) valid = false;
+        }
+        for (const DevRun& r : runs) {
+            for (uint32_t k = 0; k < r.count && valid; k++) {
+                if (!specular(r.first_object + k)) continue;
+                any = true;
+                if (r.kind == RUN_TRIANGLES) {
+                    const DevTriChunk& c = chunks[r.first_chunk + k / kTriChunk];     // (its chunk's box: a superset)
+                    for (int a = 0; a < 3; a++) {
+                        lo[a] = std::fmin(lo[a], double(c.lo[a]));
+                        hi[a] = std::fmax(hi[a], double(c.hi[a]));
+                    }
+                } else if (r.kind == RUN_SPHERES) {
+                    const DevSphereBound& b = sb[r.first_prim + k];
+                    const double reach = std::sqrt(double(b.radius2) + double(b.slack_scale) * (oo_max + double(b.magnitude2))) * 1.00001;
+                    for (int a = 0; a < 3; a++) {
+                        lo[a] = std::fmin(lo[a], double(b.center[a]) - reach);
+                        hi[a] = std::fmax(hi[a], double(b.center[a]) + reach);
+                    }
+                } else {
+                    valid = false;
+                }
+            }
+        }
+        for (int a = 0; a < 3; a++) {
+            // outward-rounded floats with a relative margin (the root test uses a 1-ulp reciprocal)
+            const double pad = 1e-5 * (std::fabs(lo[a]) + std::fabs(hi[a])) + 1e-30;
+            sc.photon_cull_lo[a] = std::nextafter(static_cast<float>(lo[a] - pad), -INFINITY);
+            sc.photon_cull_hi[a] = std::nextafter(static_cast<float>(hi[a] + pad), INFINITY);
+            valid = valid && std::isfinite(sc.photon_cull_lo[a]) && std::isfinite(sc.photon_cull_hi[a]);
+        }
+        valid = valid && any && std::isfinite(oo_max);
+        sc.photon_cull_valid = valid ? 1u : 0u;
+        sc.photon_cull_pad = 0u;
     }
     if ((rc = upload(ctx, julias, &sc.julias)) != RT_OK) return rc;
     {

@@ -1904,6 +1904,39 @@ __global__ __launch_bounds__(256) void sum_samples_kernel(const float4* __restri
     out[p] = make_float4(px.r, px.g, px.b, px.a);
 }
 
+// ---- photon roots that can leave nothing (DevScene::photon_cull_*) ----------------------------------------------
+// Direction of root (theta index, phi index): src/photonmap.cpp:42-46 on the host's sin/cos tables.
+RT_DEV V3 photon_root_direction(const DevPhotonJob& job, unsigned ti, unsigned pi) {
+    const float st = job.sin_theta[ti], ct = job.cos_theta[ti], sp_ = job.sin_phi[pi], cp = job.cos_phi[pi];
+    return normalized(v3(st * cp, st * sp_, ct));
+}
+// True when the root's ray misses the box around every object that refracts or reflects light rays.
+RT_DEV bool photon_root_passes_by(const DevScene& sc, V3 origin, V3 dir) {
+    const float4 lo = {sc.photon_cull_lo[0], sc.photon_cull_lo[1], sc.photon_cull_lo[2], 0.0f};
+    const float4 hi = {sc.photon_cull_hi[0], sc.photon_cull_hi[1], sc.photon_cull_hi[2], 0.0f};
+    return !slab_test(lo, hi, origin, cull_inverse(dir), kInfinite).overlap;
+}
+// One thread per direction (light, phi, theta) of the pass: the directions whose ray may meet a specular object, in a
+// compact list for photon_kernel (order within the list: as the waves arrive; a root keeps its own number).
+__global__ __launch_bounds__(256) void photon_cull_kernel(const DevScene sc, const DevPhotonJob job, unsigned n_dirs, uint32_t* __restrict__ live_dirs,
+                                                          unsigned long long* __restrict__ live_count) {
+    const unsigned d = blockIdx.x * 256u + threadIdx.x;
+    bool live = false;
+    if (d < n_dirs) {
+        const unsigned ti = d % job.n_theta, q = d / job.n_theta, pi = q % job.n_phi, li = q / job.n_phi;
+        const DevLight& light = sc.lights[job.point_lights[li]];
+        live = !photon_root_passes_by(sc, v3(light.position[0], light.position[1], light.position[2]), photon_root_direction(job, ti, pi));
+    }
+    const unsigned long long mask = __ballot(live);
+    if (mask == 0ull) return;
+    const unsigned lane = threadIdx.x & 63u;
+    const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+    unsigned long long base = 0;
+    if (static_cast<int>(lane) == leader) base = atomicAdd(live_count, static_cast<unsigned long long>(__popcll(mask)));
+    base = __shfl(base, leader);
+    if (live) live_dirs[base + __popcll(mask & ((1ull << lane) - 1ull))] = d;
+}
+
 // ---- photon pass (src/photonmap.cpp:20-146) ---------------------------------------------------------
 // One lane = one root direction (light, phi, theta, hue).  The path tree is walked depth first with
 // a stack of pending rays.  Deposits are RECORDED with their position in the reference's sequential pass
@@ -1946,26 +1979,44 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
     float rad[4] = {0, 0, 0, 0};
     unsigned depth = 0;
     bool need = true;
-    WaveIds wave_ids = wave_ids_begin(gid, job.n_waves, job.static_blocks);
+    // the ids to hand out: every root of the launch, or (RT_OPT_CULL_PHOTON_ROOTS) the hues of the directions that
+    // photon_cull_kernel kept — their number is known on the device only, so the split of the id space is made here
+    unsigned long long n_ids = job.n_roots, dyn_base = job.dyn_base;
+    unsigned static_blocks = job.static_blocks;
+    if (job.live_dirs != nullptr) {
+        n_ids = static_cast<unsigned long long>(*job.live_count) * job.hues;
+        static_blocks = static_cast<unsigned>(n_ids / 64ull * job.static_sixteenths / 16ull / job.n_waves);
+        dyn_base = static_cast<unsigned long long>(job.n_waves) * static_blocks * 64ull;
+    }
+    WaveIds wave_ids = wave_ids_begin(gid, job.n_waves, static_blocks);
     unsigned long long root_id = 0;      // of the tree this lane walks, and the number of its deposits so far:
     unsigned root_deposits = 0;          // together the position of a deposit in the reference's sequential pass
+    bool cullable = false;               // counters build: this root lies outside the cull box (traced all the same; must not meet a specular object)
     unsigned long long dep_next = 0, dep_end = 0;   // records this wave has reserved (wave-uniform)
     for (;;) {
         // refill idle lanes with new roots
         while (__any(need)) {
             unsigned long long id = 0;
-            const bool got = fetch_ids(job.queue_head, job.dyn_base, job.n_roots, job.id_chunk, wave_ids, need, id);
+            const bool got = fetch_ids(job.queue_head, dyn_base, n_ids, job.id_chunk, wave_ids, need, id);
             if (need) {
                 need = false;
                 if (got) {
-                    id += job.root_base;
-                    root_id = id;
-                    root_deposits = 0;
                     // (light, phi, theta, hue) of root `id`; 64-bit division costs some 150 instructions a piece, and the
                     // wave pays for the decode in every round in which a single lane starts a root
                     unsigned hue, ti, pi, li;
-                    if ((job.root_base + job.n_roots) >> 32 == 0) {
+                    if (job.live_dirs != nullptr) {
+                        // ids count the hues of the LIVE directions (photon_cull_kernel); the root keeps its number in the full pass
                         const unsigned i32 = static_cast<unsigned>(id);
+                        hue = i32 % job.hues;
+                        const unsigned dir_id = job.live_dirs[i32 / job.hues];
+                        root_id = static_cast<unsigned long long>(dir_id) * job.hues + hue;
+                        ti = dir_id % job.n_theta;
+                        const unsigned q = dir_id / job.n_theta;
+                        pi = q % job.n_phi;
+                        li = q / job.n_phi;
+                    } else if ((job.root_base + job.n_roots) >> 32 == 0) {
+                        const unsigned i32 = static_cast<unsigned>(id + job.root_base);
+                        root_id = i32;
                         hue = i32 % job.hues;
                         unsigned q = i32 / job.hues;
                         ti = q % job.n_theta;
@@ -1973,6 +2024,8 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                         pi = q % job.n_phi;
                         li = q / job.n_phi;
                     } else {
+                        id += job.root_base;
+                        root_id = id;
                         hue = static_cast<unsigned>(id % job.hues);
                         unsigned long long q = id / job.hues;
                         ti = static_cast<unsigned>(q % job.n_theta);
@@ -1980,9 +2033,13 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                         pi = static_cast<unsigned>(q % job.n_phi);
                         li = static_cast<unsigned>(q / job.n_phi);
                     }
+                    root_deposits = 0;
                     const DevLight& light = T.lights[job.point_lights[li]];
-                    const float st = job.sin_theta[ti], ct = job.cos_theta[ti], sp_ = job.sin_phi[pi], cp = job.cos_phi[pi];
-                    const V3 dir = normalized(v3(st * cp, st * sp_, ct));
+                    const V3 origin = v3(light.position[0], light.position[1], light.position[2]);
+                    const V3 dir = photon_root_direction(job, ti, pi);
+                    // the counters build traces every root and checks what photon_cull_kernel claims of those it would drop
+                    cullable = STATS && sc.photon_cull_valid != 0u && photon_root_passes_by(sc, origin, dir);
+                    if (cullable) bump<STATS>(n, C_PHOTON_ROOTS_CULLED);
                     if (sc.dispersion) {
                         // HSVtoRGB(h) * factor / 4
                         for (int c = 0; c < 4; c++) rad[c] = (sc.hue[hue][c] * sc.photon_factor) / 4.0f;
@@ -1993,7 +2050,7 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                     }
                     depth = 0;
                     L.sp = 0;
-                    begin_query(L, v3(light.position[0], light.position[1], light.position[2]), dir, kInfinite, Q_PHOTON);
+                    begin_query(L, origin, dir, kInfinite, Q_PHOTON);
                 }
             }
         }
@@ -2031,6 +2088,7 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                         for (int c = 0; c < 4; c++) deposit_rad[c] = rad[c];
                     }
                 } else if (depth + 1 <= sc.max_bounces) {
+                    if (STATS && cullable) n.v[D_PHOTON_CULL_VIOLATIONS]++;
                     const float cosv = clampf(dot(L.qd, L.best.normal), -1.0f, 1.0f);
                     bump<STATS>(n, C_FRESNEL);
                     const float kr = fresnel_kr(m.refr_re, m.refr_im, m.dispersion, cosv, L.wavelength);

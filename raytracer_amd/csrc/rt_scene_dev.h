@@ -159,6 +159,15 @@ struct DevScene {
     float4* photon_atlas;              // [n_slots][size][size]
     uint32_t photon_size;
     float photon_factor;
+    // Photon roots (src/photonmap.cpp:38-58): a light ray deposits only after a specular bounce (:79-83), so a root
+    // that cannot meet a specular object leaves nothing.  Box around every object whose material refracts or reflects
+    // light rays (refr_norm > 0), conservative for the intersectors as written (triangle boxes as in DevTriChunk, spheres
+    // by DevSphereBound with its rounding slack at the lights' positions); valid = 0 when such an object has no finite
+    // bound (a Julia set, a degenerate triangle, a wild transform) or there is none.
+    float photon_cull_lo[3];
+    uint32_t photon_cull_valid;
+    float photon_cull_hi[3];
+    uint32_t photon_cull_pad;
 };
 
 // One render call's partition of the image (rt_bands) and where its samples go.
@@ -213,7 +222,11 @@ struct DevPhotonJob {
     uint32_t dep_capacity;
     uint32_t dep_seq_bits;          // key = texel << (dep_root_bits + dep_seq_bits) | root << dep_seq_bits | seq
     uint32_t dep_root_bits;
-    uint32_t dep_pad;
+    uint32_t static_sixteenths;     // share of the ids handed out as static blocks (for the split the kernel makes itself, below)
+    // RT_OPT_CULL_PHOTON_ROOTS and no counters: the pass runs over the directions photon_cull_kernel kept (those whose ray
+    // may meet a specular object, DevScene::photon_cull_*) instead of over all of them.  NULL: every root.
+    const uint32_t* live_dirs;              // direction = (light * n_phi + phi) * n_theta + theta
+    const unsigned long long* live_count;   // how many (device memory: known only after photon_cull_kernel ran)
 };
 constexpr uint32_t kDepositChunk = 32;      // records a wave reserves per atomic
 constexpr uint32_t kDepositLongRun = 32;    // deposits into one texel from which a wave sums them (rt_photon_order.hip)
@@ -242,7 +255,7 @@ constexpr uint32_t kJuliaStaticLdsBytes = 160 * 1024;    // its static LDS (pool
 enum CounterSlot : int {
     C_PRIMARY = 0, C_SECONDARY, C_SHADOW, C_PHOTON_SEGMENTS, C_PHOTON_DEPOSITS, C_SPHERE_TESTS, C_TRIANGLE_TESTS,
     C_JULIA_QUERIES, C_JULIA_STEPS, C_JULIA_DE_ITERATIONS, C_JULIA_NORMALS, C_SHADED_HITS, C_PHONG_LIGHTS,
-    C_FRESNEL, C_TEXTURE_LOOKUPS, C_BVH_NODE_VISITS, C_SHADOW_ELIDED,
+    C_FRESNEL, C_TEXTURE_LOOKUPS, C_BVH_NODE_VISITS, C_SHADOW_ELIDED, C_PHOTON_ROOTS_CULLED,
     // scheduler diagnostics (rt_debug_counters; not part of rt_stats)
     D_QUERY_PHASES, D_QUERY_LANES, D_MARCH_PHASES, D_MARCH_LANES, D_NORMAL_PHASES, D_NORMAL_LANES,
     D_RESOLVE_PHASES, D_RESOLVE_LANES, D_DE_WAVE_ITERS,
@@ -255,6 +268,7 @@ enum CounterSlot : int {
     D_MARCH_POLLS,
     D_CHUNK_TESTS, D_CHUNK_PASSED, D_CHUNK_LANES, D_SPHERE_CULLS, D_SPHERE_PASSED,   // wave-level: chunk / sphere cull tests made, not culled; lanes overlapping a passed chunk
     D_RESOLVE_MIXED, D_RESOLVE_MINORITY_LANES,   // trace_kernel: resolve phases holding both ray results and shadow results; lanes of the rarer kind in them
+    D_PHOTON_CULL_VIOLATIONS,   // photon_kernel, counters build: roots outside DevScene::photon_cull_* that met a specular object all the same (must stay 0)
     C_COUNT
 };
 

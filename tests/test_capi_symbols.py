@@ -39,7 +39,7 @@ def test_struct_sizes_match_the_header():
     assert ctypes.sizeof(capi.Triangle) == 96
     assert ctypes.sizeof(capi.Julia) == 36 + 3 * 48
     assert ctypes.sizeof(capi.Object) == 12
-    assert ctypes.sizeof(capi.Stats) == 16 * 8 + 8 + 8      # 16 counters, kernel_ms, shadow_rays_elided
+    assert ctypes.sizeof(capi.Stats) == 16 * 8 + 8 + 8 + 8      # 16 counters, kernel_ms, shadow_rays_elided, photon_roots_culled
 
 
 def test_pure_host_entry_points():

@@ -402,6 +402,39 @@ def test_photon_atlas_vs_oracle(hip_ctx):
             assert oracle_lib.image_diff(capi.quantize(img), capi.quantize(ref))["frac_gt1"] == 0.0
 
 
+@pytest.mark.parametrize("source", ["examples3/103_caustic_steps200.xml", 1, 9, 13, 21, 25, 33, 5, 29])
+def test_photon_roots_that_can_leave_nothing_are_not_traced(hip_ctx, source, tmp_path):
+    """The reference deposits a light ray only after a specular bounce (src/photonmap.cpp:79-83), so a root whose ray
+    passes the box around every refracting or reflecting object by leaves nothing.  The plain pass skips those roots
+    (RT_OPT_CULL_PHOTON_ROOTS); the counters pass traces them, says how many there are and counts any that met a specular
+    object all the same (none may).  Photon textures with the option on and off: the oracle's, bit for bit."""
+    if isinstance(source, int):
+        from mesh_scene import write_random_scene
+        sc = capi.Scene(write_random_scene(tmp_path, source), 0.0)
+    else:
+        sc = capi.Scene(scene_path(source), 0.5)
+    ph = oracle_lib.Photons(sc)
+    hip_ctx.upload(sc)
+    hip_ctx.set_option(capi.RT_OPT_COLLECT_STATS, 1)
+    st = hip_ctx.photon_generate()
+    hip_ctx.set_option(capi.RT_OPT_COLLECT_STATS, 0)
+    words = (C.c_uint64 * 128)()
+    nw = capi.hip_lib().rt_debug_counters(hip_ctx._ctx, words, 128)
+    assert words[nw - 1] == 0                      # D_PHOTON_CULL_VIOLATIONS, the last slot
+    assert st.photon_segments == ph.stats.photon_segments and st.photon_deposits == ph.stats.photon_deposits
+    assert st.photon_roots_culled < st.photon_segments
+    if not isinstance(source, int):
+        assert st.photon_roots_culled > 0.8 * st.photon_segments      # the glass box is small from where the lights are (segments include the bounces)
+    try:
+        for on in (1, 0):
+            hip_ctx.set_option(capi.RT_OPT_CULL_PHOTON_ROOTS, on)
+            hip_ctx.photon_generate()
+            for o in range(sc.desc.n_objects):
+                assert np.array_equal(hip_ctx.photon_download(o).view(np.uint32), ph.texture(o).view(np.uint32)), (on, o)
+    finally:
+        hip_ctx.set_option(capi.RT_OPT_CULL_PHOTON_ROOTS, 1)
+
+
 def test_photon_record_buffer_grows_when_a_scene_outgrows_it(hip_ctx):
     """A record buffer far too small for the scene's deposits: rt_photon_generate must notice, resize from
     what the pass reported, run again and return the reference's textures; the asynchronous entry point

@@ -58,8 +58,8 @@ def main():
                      "step_blocks_1", "step_blocks_2", "step_blocks_4", "step_blocks_8", "step_blocks_16", "step_blocks_32", "step_blocks_more",
                      "step_class_switch", "step_block_sum", "ring_samples", "ring_march_sum", "ring_normal_sum", "ring_ready_t_sum", "ring_ready_s_sum",
                      "march_has_sum", "march_polls", "chunk_tests", "chunk_passed", "chunk_lanes", "sphere_culls", "sphere_passed",
-                     "resolve_mixed", "resolve_minority_lanes"]
-            dbg = dict(zip(names, list(words)[17:nw]))
+                     "resolve_mixed", "resolve_minority_lanes", "photon_cull_violations"]
+            dbg = dict(zip(names, list(words)[18:nw]))
             print("  scheduler", dbg, flush=True)
             for ph in ("query", "march", "normal", "resolve"):
                 if dbg[ph + "_phases"]:

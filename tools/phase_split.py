@@ -13,6 +13,6 @@ for path in sys.argv[1:]:
     capi.hip_lib().rt_debug_counters(ctx._ctx, words, 96)
     w = list(words)
     names = ["query_phases", "query_lanes", "march_phases", "march_lanes", "normal_phases", "normal_lanes", "resolve_phases", "resolve_lanes", "de", "query_cycles", "march_cycles", "normal_cycles", "resolve_cycles"]
-    d = dict(zip(names, w[17:17 + len(names)]))
+    d = dict(zip(names, w[18:18 + len(names)]))
     q, r = d["query_cycles"], d["resolve_cycles"]
     print(os.path.basename(path), "kernel ms %.3f" % st.kernel_ms, "query share %.3f" % (q / max(1, q + r)), "phases", d["query_phases"], "clk/query phase %.0f" % (q / max(1, d["query_phases"])), "clk/resolve phase %.0f" % (r / max(1, d["query_phases"])))
