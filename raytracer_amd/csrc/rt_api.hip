@@ -846,7 +846,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
         if (lights[i].type == 1) ctx->point_lights.push_back(i);
     }
     sc.n_lights = d->n_lights;
-    // DevMaterial::unlit / resolve_lane: a light is benign when nothing about it can turn a product with zero into a NaN
+    // DevMaterial::phong_tame / resolve_lane: a light is benign when nothing about it can turn a product with zero into a NaN
     auto tame = [](float v) { return std::fabs(v) <= 1e18f; };     // (false for NaN)
     sc.lights_benign = 1u;
     for (const DevLight& l : lights) {
@@ -867,7 +867,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
         o.reflectance = m.reflectance; o.transmittance = m.transmittance;
         o.refr_re = m.refraction_re; o.refr_im = m.refraction_im; o.dispersion = m.dispersion;
         o.refr_norm = m.refraction_re * m.refraction_re + m.refraction_im * m.refraction_im;   // std::norm
-        o.unlit = (m.kd == 0.0f && m.ks == 0.0f && m.exponent >= 0.0f && m.exponent <= 1e6f && tame(m.color[0]) && tame(m.color[1]) && tame(m.color[2])) ? 1u : 0u;
+        o.phong_tame = (tame(m.kd) && tame(m.ks) && m.exponent >= 0.0f && m.exponent <= 1e6f && tame(m.color[0]) && tame(m.color[1]) && tame(m.color[2])) ? 1u : 0u;
     }
     std::vector<DevTexture> texs(d->n_textures);
     std::vector<uint32_t> texels;     // RGBA8 as given; the kernels form u8 / 255.0f themselves (rt_intersect.h: unorm8)

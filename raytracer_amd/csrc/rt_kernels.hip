@@ -641,17 +641,28 @@ __device__ __attribute__((noinline)) float specular_pow(float base, float expone
     return static_cast<float>(pow(static_cast<double>(base), static_cast<double>(exponent)));
 }
 
-// First light at or after `li` whose shadow ray has to be traced from an unlit surface point (resolve_lane explains);
-// kept out of line: inlined, its few live values cost the Julia kernel 70 more spilled VGPRs.
+// First light at or after `li` whose shadow ray has to be traced: lights that can only add +-0 at this point are passed
+// over (resolve_lane explains).  Out of line: inlined, its few live values cost the Julia kernel 70 more spilled VGPRs.
+// The light direction, Lambert term, reflected direction and specular base are formed exactly as begin_shadow and the
+// shading code form them (src/raytracer.cpp:214-233), so "zero" here is the zero they would multiply by.
 template <bool STATS>
-__device__ __attribute__((noinline)) unsigned skip_unlit_lights(const DevLight* lights, unsigned n_lights, unsigned li, V3 point, V3 normal, bool elide, Counters& n) {
+__device__ __attribute__((noinline)) unsigned skip_dark_lights(const DevLight* lights, unsigned n_lights, unsigned li, V3 point, V3 normal, V3 view_dir,
+                                                               float kd, float ks, float exponent, bool elide, Counters& n) {
     if (!(fabsf(point.x) + fabsf(point.y) + fabsf(point.z) < __builtin_inff() && fabsf(normal.x) + fabsf(normal.y) + fabsf(normal.z) < __builtin_inff())) return li;
     while (li < n_lights) {
         const DevLight& light = lights[li];
-        if (light.type != 0) {
-            const V3 d = v3(light.position[0], light.position[1], light.position[2]) - point;
-            const float dd = dot(d, d);
-            if (!(dd > 0.0f && dd < __builtin_inff())) break;
+        const V3 lpos = v3(light.position[0], light.position[1], light.position[2]);
+        const V3 to_light = light.type == 0 ? lpos * -1.0f : lpos - point;
+        const float dd = dot(to_light, to_light);
+        if (!(dd > 0.0f && dd < __builtin_inff())) break;
+        const V3 dir = normalized(to_light);
+        const float ndotl = dot(dir, normal);
+        if (!(kd == 0.0f || ndotl <= 0.0f)) break;                  // max(ndotl, 0) * kd != 0: lit
+        if (ks != 0.0f) {
+            if (!(exponent > 0.0f)) break;                          // pow(0, 0) = 1
+            const V3 refl = normalized(normal * ndotl * 2.0f - dir);
+            const float rv = dot(refl, view_dir * -1.0f);
+            if (!(rv <= 0.0f)) break;                               // max(rv, 0) != 0 (or NaN): a highlight is possible
         }
         bump<STATS>(n, C_SHADOW_ELIDED);
         if (!elide) break;
@@ -758,16 +769,29 @@ RT_DEV void resolve_lane(const DevScene& sc, const ShadeTables& T, const DevJob&
 
     mark<STATS>(n, t_sec, L.qkind == Q_TRACE ? D_R_NODE_CYCLES : D_R_LIGHT_CYCLES);
     if (!returning && !lights_done) {
-        // Lights that can only add +-0.  On a surface with kd == 0 and ks == 0 (a mirror, clear glass) the reference
-        // still casts a shadow ray per light and then adds power*colour*lambert*0 + power*pow(..)*0 if it is not
-        // blocked (src/raytracer.cpp:214-235): +-0 onto a sum that is +0 or non-zero, i.e. nothing, blocked or not —
-        // provided none of the factors is infinite or NaN, which is what DevMaterial::unlit, DevScene::lights_benign
-        // and the checks below establish (finite point and unit normal, a light direction of finite non-zero
-        // length; then lambert, the reflected direction and pow's base are finite and pow <= e^0.25).  Such rays
-        // are not traced.  A counters launch traces them (its counts are those of the reference's formulation)
-        // and reports how many the plain launch skips.
-        if (L.li < sc.n_lights && sc.lights_benign != 0u && T.materials[T.object_material[L.n_obj]].unlit != 0u)
-            L.li = skip_unlit_lights<STATS>(T.lights, sc.n_lights, L.li, L.n_point, L.n_normal, job.elide_unlit != 0u, n);
+        // Lights that can only add +-0.  The reference casts a shadow ray per light and, if it is not blocked, adds
+        // power*colour*max(n.l, 0)*kd + power*pow(max(r.v, 0), exponent)*ks (src/raytracer.cpp:214-235).  Where the light
+        // is behind the surface (n.l <= 0) or kd == 0, and the mirrored light direction points away from the viewer
+        // (r.v <= 0, exponent > 0: pow(0, e) = 0) or ks == 0 — the back of every object as seen from a light, all of a
+        // mirror or of clear glass — that is +-0 onto a sum that is +0 or non-zero (it starts as 0.0f + ambient term),
+        // i.e. nothing, blocked or not, provided no factor is infinite or NaN: DevMaterial::phong_tame,
+        // DevScene::lights_benign and skip_dark_lights' checks (finite point and normal, a light direction of finite
+        // non-zero length; then n.l, the reflected direction and pow's base are finite and pow <= e^0.25) see to that.
+        // Such rays are not traced.  A counters launch traces them (its counts are those of the reference's formulation)
+        // and reports how many the plain launch skips.  (The test in front of the call is a filter only: the sign of n.l
+        // before the direction is normalised; the function decides on the values the shading code would use.)
+        if (L.li < sc.n_lights && sc.lights_benign != 0u) {
+            const DevMaterial& m = T.materials[T.object_material[L.n_obj]];
+            if (m.phong_tame != 0u) {
+                bool maybe = m.kd == 0.0f;
+                if (!maybe) {
+                    const DevLight& light = T.lights[L.li];
+                    const V3 lpos = v3(light.position[0], light.position[1], light.position[2]);
+                    maybe = dot(light.type == 0 ? lpos * -1.0f : lpos - L.n_point, L.n_normal) <= 0.0f;
+                }
+                if (maybe) L.li = skip_dark_lights<STATS>(T.lights, sc.n_lights, L.li, L.n_point, L.n_normal, L.n_dir, m.kd, m.ks, m.exponent, job.elide_unlit != 0u, n);
+            }
+        }
         if (L.li < sc.n_lights) {
             begin_shadow(T, L);
             mark<STATS>(n, t_sec, D_R_SHADOWSETUP_CYCLES);

@@ -70,7 +70,7 @@ struct DevMaterial {
     float reflectance, transmittance;
     float refr_re, refr_im, dispersion;
     float refr_norm;         // re*re + im*im (std::norm)
-    uint32_t unlit;          // 1: kd == 0 and ks == 0 with tame colour and exponent: every light adds exactly +-0 here (resolve_lane)
+    uint32_t phong_tame;     // 1: colour, kd and ks finite and modest, exponent in [0, 1e6]: a light whose diffuse and specular factors are zero adds exactly +-0 here (resolve_lane)
 };
 struct DevTexture {
     uint32_t width, height;
@@ -153,7 +153,7 @@ struct DevScene {
     uint32_t shade_blob_in_lds;        // 0/1, decided by the host from the blob size
     uint32_t bvh_records_in_lds;       // > 0: the scene's BVH records (all runs, this many) are few enough to be copied into LDS
     uint32_t frame_slots_in_lds;       // trace_kernel: newest frames of a lane kept in LDS, 1 or 2 (TopInLds)
-    uint32_t lights_benign;            // 0/1: every light has a tame power and position (see DevMaterial::unlit)
+    uint32_t lights_benign;            // 0/1: every light has a tame power and position (see DevMaterial::phong_tame)
     uint32_t bvh_lds_stack_entries;    // per-lane BVH stack entries kept in LDS (behind the blob copy); deeper ones go to scratch
 
     float4* photon_atlas;              // [n_slots][size][size]

@@ -604,12 +604,14 @@ def test_depth_of_field(hip_ctx):
 
 
 @pytest.mark.parametrize("rel,t", [("examples2/8_fresnel.xml", 0.0), ("examples3/103_caustic_animation.xml", 0.5),
-                                   ("examples3/101_julia_shiny.xml", 0.0)])
+                                   ("examples3/101_julia_shiny.xml", 0.0), ("examples/example9_lowres.xml", 0.0),
+                                   ("examples/example8.xml", 0.0), ("examples2/1_transparent.xml", 0.0)])
 def test_shadow_rays_that_can_only_add_zero_are_not_traced(hip_ctx, rel, t):
-    """On a surface with kd == ks == 0 (the glass and mirror objects of C3, C4, C5) the reference casts a shadow ray per
-    light and multiplies what it finds by zero.  The plain launch skips those rays (RT_OPT_ELIDE_UNLIT_SHADOWS), the
-    counters launch traces them and says how many there are: same float picture bit for bit, with the option on or off,
-    as the oracle's, and the plain launch is not slower."""
+    """Where a light is behind the surface or kd == 0, and its mirrored direction points away from the viewer or ks == 0
+    (the back of every object as seen from a light; all of the glass and mirror objects of C3, C4, C5), the reference
+    casts a shadow ray and multiplies what it finds by zero.  The plain launch skips those rays
+    (RT_OPT_ELIDE_UNLIT_SHADOWS), the counters launch traces them and says how many there are: same float picture bit
+    for bit, with the option on or off, as the oracle's."""
     sc = capi.Scene(scene_path(rel), t)
     if sc.desc.n_julias > 0:
         sc.set_camera(240, 150, 0)
