@@ -159,7 +159,8 @@ __global__ void bvh_pack_kernel(const DevBvhNode* __restrict__ nodes, int n, Dev
     }
     p.child0 = a.count == kBvhLeaf ? (kBvhLeafBit | a.left_or_first) : nodes[i].left_or_first;
     p.child1 = b.count == kBvhLeaf ? (kBvhLeafBit | b.left_or_first) : nodes[i].count;
-    p.pad0 = p.pad1 = 0;
+    p.slack0 = 1e-4f * ((a.hi[0] - a.lo[0]) + (a.hi[1] - a.lo[1]) + (a.hi[2] - a.lo[2]));
+    p.slack1 = 1e-4f * ((b.hi[0] - b.lo[0]) + (b.hi[1] - b.lo[1]) + (b.hi[2] - b.lo[2]));
     pairs[i] = p;
 }
 
@@ -311,7 +312,8 @@ struct HostBuilder {
         }
         p.child0 = c0;
         p.child1 = c1;
-        p.pad0 = p.pad1 = 0;
+        p.slack0 = 1e-4f * ((b0.hi[0] - b0.lo[0]) + (b0.hi[1] - b0.lo[1]) + (b0.hi[2] - b0.lo[2]));
+        p.slack1 = 1e-4f * ((b1.hi[0] - b1.lo[0]) + (b1.hi[1] - b1.lo[1]) + (b1.hi[2] - b1.lo[2]));
         return me;
     }
 };

@@ -218,7 +218,8 @@ struct SlabHit {
     bool overlap;
     float tnear;
 };
-RT_DEV SlabHit slab_test(float4 lo, float4 hi, V3 o, V3 inv, float qmax) {
+RT_DEV float slab_slack(float4 lo, float4 hi) { return 1e-4f * ((hi.x - lo.x) + (hi.y - lo.y) + (hi.z - lo.z)); }
+RT_DEV SlabHit slab_test(float4 lo, float4 hi, V3 o, V3 inv, float qmax, float t_slack) {
     // fminf/fmaxf drop the NaNs of 0*inf so that an axis-parallel ray lying in a face plane is kept; the far side
     // is widened by 8 ulp (robust traversal with the 1-ulp reciprocal of cull_inverse)
     const float x0 = (lo.x - o.x) * inv.x, x1 = (hi.x - o.x) * inv.x;
@@ -231,7 +232,7 @@ RT_DEV SlabHit slab_test(float4 lo, float4 hi, V3 o, V3 inv, float qmax) {
     // and the test may then put the hit a few ulp in front of the box.  The scan accepts t == maximum (an
     // exact tie goes to the later object), so a box is skipped only when it lies beyond the maximum by
     // more than that noise can be (1e-4 of the distance and of the box: ~10^3 ulp, no measurable cost).
-    const float t_slack = 1e-4f * ((hi.x - lo.x) + (hi.y - lo.y) + (hi.z - lo.z));
+    // (t_slack = slab_slack(lo, hi); the BVH records carry it in their spare words)
     SlabHit h;
     h.overlap = !(tnear > tfar * 1.000001f) && !(tfar < -t_slack) && !(tnear * 0.9999f - t_slack > qmax);
     h.tnear = tnear;
@@ -276,7 +277,7 @@ RT_DEV void query_bvh(const DevScene& sc, Lane& L, unsigned act, unsigned bvh_ro
             bump<STATS>(n, C_BVH_NODE_VISITS, 2);
             const float4* raw = reinterpret_cast<const float4*>(fast.nodes + bvh_root + cur);
             const float4 lo0 = raw[0], hi0 = raw[1], lo1 = raw[2], hi1 = raw[3];
-            const SlabHit h0 = slab_test(lo0, hi0, L.qo, inv, L.qmax), h1 = slab_test(lo1, hi1, L.qo, inv, L.qmax);
+            const SlabHit h0 = slab_test(lo0, hi0, L.qo, inv, L.qmax, lo1.w), h1 = slab_test(lo1, hi1, L.qo, inv, L.qmax, hi1.w);
             const unsigned c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(hi0.w);
             if (h0.overlap && h1.overlap) {
                 const bool first0 = h0.tnear <= h1.tnear;
@@ -1938,7 +1939,7 @@ RT_DEV V3 photon_root_direction(const DevPhotonJob& job, unsigned ti, unsigned p
 RT_DEV bool photon_root_passes_by(const DevScene& sc, V3 origin, V3 dir) {
     const float4 lo = {sc.photon_cull_lo[0], sc.photon_cull_lo[1], sc.photon_cull_lo[2], 0.0f};
     const float4 hi = {sc.photon_cull_hi[0], sc.photon_cull_hi[1], sc.photon_cull_hi[2], 0.0f};
-    return !slab_test(lo, hi, origin, cull_inverse(dir), kInfinite).overlap;
+    return !slab_test(lo, hi, origin, cull_inverse(dir), kInfinite, slab_slack(lo, hi)).overlap;
 }
 // One thread per direction (light, phi, theta) of the pass: the directions whose ray may meet a specular object, in a
 // compact list for photon_kernel (order within the list: as the waves arrive; a root keeps its own number).

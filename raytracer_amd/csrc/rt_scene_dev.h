@@ -109,9 +109,9 @@ struct DevBvhPair {
     float hi0[3];
     uint32_t child1;
     float lo1[3];
-    uint32_t pad0;
+    float slack0;     // distance slack of the slab test (rt_kernels.hip: slab_test) for child 0's box: 1e-4 of its extents' sum
     float hi1[3];
-    uint32_t pad1;
+    float slack1;     // ... for child 1's
 };
 
 struct DevScene {
