@@ -51,19 +51,56 @@ class HipRenderer:
         self.busy_events = None      # a list: render() then brackets its GPU work with event pairs (bench.py)
 
     def busy_seconds(self):
-        """GPU time of the render() calls since busy_events was set to a list; clears the list."""
+        """GPU time of the render() calls (this renderer's and its twin's: render_units) since busy_events was set to a
+        list — the union of their intervals, which overlap when two units are in flight; clears the list."""
         torch.cuda.synchronize()
-        total = sum(a.elapsed_time(b) for a, b in self.busy_events) * 1e-3
+        pairs = list(self.busy_events)
+        twin = getattr(self, "_twin", None)
+        if twin is not None and twin.busy_events:
+            pairs += twin.busy_events
+            twin.busy_events = []
         self.busy_events = []
-        return total
+        if not pairs:
+            return 0.0
+        base = pairs[0][0]
+        spans = sorted((base.elapsed_time(a), base.elapsed_time(b)) for a, b in pairs)
+        total, end = 0.0, None
+        for lo, hi in spans:
+            if end is None or lo > end:
+                total += hi - lo
+                end = hi
+            elif hi > end:
+                total += hi - end
+                end = hi
+        return total * 1e-3
 
-    def _photon_pass(self, enqueue):
+    def lanes(self):
+        """[(renderer, stream)] that render_units alternates its units over: this renderer and a twin (a second context on
+        the same GPU) on two side streams, so that the photon pass of one unit runs beside the trace kernel of the one
+        before — either leaves half of the GPU idle on frames of C5's size.  RT_DRIVER_OVERLAP=0: this renderer alone
+        on the current stream."""
+        if os.environ.get("RT_DRIVER_OVERLAP", "1") in ("", "0"):
+            return [(self, None)]
+        if getattr(self, "_twin", None) is None:
+            self._twin = HipRenderer(self.device.index)
+            self._streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+        self._twin.busy_events = [] if self.busy_events is not None else None
+        return [(self, self._streams[0]), (self._twin, self._streams[1])]
+
+    def _photon_pass(self, enqueue, defer_check=False):
         """Enqueues a photon pass; if it outgrew the record buffer of the ordered sum (the library has resized it
-        by then) the pass runs once more, so that the textures are the reference's bit for bit."""
+        by then) the pass runs once more, so that the textures are the reference's bit for bit.  defer_check: the
+        caller asks photon_pass_ok() later (asking waits for the pass) and renders again if need be."""
         stream = torch.cuda.current_stream().cuda_stream
         enqueue(stream)
-        if self.ctx.ordered_photons and not self.ctx.photon_ordered():
+        self._unchecked_pass = defer_check and self.ctx.ordered_photons
+        if not defer_check and self.ctx.ordered_photons and not self.ctx.photon_ordered():
             enqueue(stream)
+
+    def photon_pass_ok(self):
+        """False if the last render(..., defer_check=True) has to be made again (its photon pass outgrew the record buffer)."""
+        unchecked, self._unchecked_pass = getattr(self, "_unchecked_pass", False), False
+        return not unchecked or self.ctx.photon_ordered()
 
     def photon_pass(self, scene, part, n_parts):
         """Uploads the scene and emits slice `part` of `n_parts` of its photon pass.  Returns the photon
@@ -76,15 +113,16 @@ class HipRenderer:
             return None
         return torch.as_tensor(_DeviceFloats(ptr, n), device=self.device)
 
-    def render(self, scene, bands=None, photons_ready=False):
+    def render(self, scene, bands=None, photons_ready=False, defer_check=False):
         stream = torch.cuda.current_stream().cuda_stream
+        self._unchecked_pass = False
         if self.busy_events is not None:
             pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             pair[0].record()
         if not photons_ready:      # (an upload clears the photon textures)
             self.ctx.upload(scene)
             if scene.desc.photon_steps > 0:
-                self._photon_pass(self.ctx.photon_generate_device)
+                self._photon_pass(self.ctx.photon_generate_device, defer_check)
         n = self.ctx.pixel_count(bands)
         out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         if n:
@@ -258,27 +296,60 @@ def render_units(renderer, path, units, consume, payload=None):
                 if j < len(units):
                     consume(units[j], pics[r])
 
+    lanes = renderer.lanes() if hasattr(renderer, "lanes") else [(renderer, None)]
+    two = len(lanes) == 2
+    raw = [None, None]        # two lanes: (picture, scene) of a unit whose photon pass has not been confirmed yet
+
+    def finish(i, out):
+        """Round i's payload is on its way: hand it to the gather, after consuming round i-2 (whose buffers it takes)."""
+        if i >= 2:
+            consume_round(i - 2)
+        b = i % 2
+        bufs[b] = out
+        if collective:
+            if rank == 0:
+                # fresh tensors every round (the caching allocator makes that cheap): consumers may still be reading
+                # the previous ones on another stream (HostFrames), which record_stream keeps alive, not unwritten
+                gathered[b] = [torch.empty_like(out) for _ in range(world)]
+            pending[b] = dist.gather(out, gathered[b] if rank == 0 else None, dst=0, async_op=True)
+
+    def confirm(i):
+        """Two lanes: unit i was enqueued a round ago with its photon pass unchecked (asking waits for the pass, and the
+        host has the next unit to upload meanwhile).  Confirms it, renders it again in the rare case that the pass outgrew
+        its record buffer, and sends the payload on."""
+        lane, side = lanes[i % 2]
+        pic, scene = raw[i % 2]
+        raw[i % 2] = None
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(side):
+            if not lane.photon_pass_ok():
+                pic = lane.render(scene)
+            out = payload(pic)
+        out.record_stream(main)
+        main.wait_stream(side)          # what follows on the main stream (gather, consume) sees the finished picture
+        finish(i, out)
+
     with ThreadPoolExecutor(max_workers=1) as pool:
         nxt = pool.submit(load, 0) if rounds else None
         for i in range(rounds):
             scene = nxt.result()
             nxt = pool.submit(load, i + 1) if i + 1 < rounds else None
-            b = i % 2
-            if scene is not None:
-                out = payload(renderer.render(scene))
-            else:
+            if scene is None:
                 # a rank without a unit in the last round still takes part in the gather
+                if two and i >= 1 and raw[(i - 1) % 2] is not None:
+                    confirm(i - 1)
                 probe = capi.Scene(path, units[0][2])
-                out = payload(torch.zeros((probe.width * probe.height, 4), dtype=torch.float32, device=device))
-            if i >= 2:
-                consume_round(i - 2)               # round i is already on the GPU's queue
-            bufs[b] = out
-            if collective:
-                if rank == 0:
-                    # fresh tensors every round (the caching allocator makes that cheap): consumers may still be reading
-                    # the previous ones on another stream (HostFrames), which record_stream keeps alive, not unwritten
-                    gathered[b] = [torch.empty_like(out) for _ in range(world)]
-                pending[b] = dist.gather(out, gathered[b] if rank == 0 else None, dst=0, async_op=True)
+                finish(i, payload(torch.zeros((probe.width * probe.height, 4), dtype=torch.float32, device=device)))
+            elif two:
+                lane, side = lanes[i % 2]
+                with torch.cuda.stream(side):
+                    raw[i % 2] = (lane.render(scene, defer_check=True), scene)
+                if i >= 1 and raw[(i - 1) % 2] is not None:
+                    confirm(i - 1)              # round i is already on the GPU's queue
+            else:
+                finish(i, payload(renderer.render(scene)))
+        if two and rounds >= 1 and raw[(rounds - 1) % 2] is not None:
+            confirm(rounds - 1)
         for i in range(max(0, rounds - 2), rounds):
             consume_round(i)
 

@@ -344,6 +344,39 @@ def test_rccl_gathers_of_the_pipelined_driver(monkeypatch):
         dist.destroy_process_group()
 
 
+def test_units_alternating_over_two_contexts_give_the_same_frames(monkeypatch):
+    """driver.render_units alternates its units over two contexts on two streams (the photon pass of one unit beside the
+    trace kernel of the one before) and confirms a unit's photon pass a round late.  The frames must be those of one
+    context on one stream and of the lock-step loop — also when every photon pass is found too small for its record
+    buffer at first and the unit is rendered again (a fresh pair of contexts with a tiny buffer)."""
+    from raytracer_amd import driver
+    files = [scene_path("examples3/103_caustic_animation.xml"), scene_path("examples3/103_caustic_animation_mb8.xml")]
+    monkeypatch.setenv("RT_DRIVER_SEQUENTIAL", "1")
+    want = [driver.render_frames(driver.HipRenderer(0), f)[0] for f in files]
+    monkeypatch.setenv("RT_DRIVER_SEQUENTIAL", "0")
+    for overlap in ("0", "1"):
+        monkeypatch.setenv("RT_DRIVER_OVERLAP", overlap)
+        r = driver.HipRenderer(0)
+        for f, frames in zip(files, want):
+            got = driver.render_frames(r, f)[0]
+            assert len(got) == len(frames)
+            for a, b in zip(got, frames):
+                assert np.array_equal(a, b), overlap
+    monkeypatch.setenv("RT_DRIVER_OVERLAP", "1")
+    r = driver.HipRenderer(0)
+    lanes = r.lanes()
+    assert len(lanes) == 2 and lanes[0][0] is r
+    reruns = []
+    for lane, _stream in lanes:
+        lane.ctx.set_option(capi.RT_OPT_PHOTON_RECORDS, 4096)       # far too few: the first pass of each context overflows
+        ok = lane.photon_pass_ok
+        lane.photon_pass_ok = (lambda ok=ok: reruns.append(ok()) or reruns[-1])
+    got = driver.render_frames(r, files[0])[0]
+    assert reruns.count(False) >= 2
+    for a, b in zip(got, want[0]):
+        assert np.array_equal(a, b)
+
+
 # The reference built with its OWN Makefile flags (-Ofast -flto -march=native) is the secondary parity
 # target (SURVEY 8c): fast-math reorders its arithmetic, so the bar against it is the reference's own
 # flag noise — what its O-strict and O-fast builds differ by (tests/test_oracle_golden.py asserts those
