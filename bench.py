@@ -438,6 +438,7 @@ def main():
             "config": {"workload": label, "scene": rel, "t": t, "rays_per_frame": rays_per_step,
                        "photon_roots_culled_per_frame": stats.get("photon_roots_culled", 0),   # of the photon pass's roots, counted in rays_per_frame, dropped before the pass: DESIGN.md 4.6
                        "shadow_rays_elided_per_frame": stats.get("shadow_rays_elided", 0),   # counted in rays_per_frame (rays of the reference's formulation), not traced: DESIGN.md 4.4
+                       "rays_traced_per_frame": rays_per_step - stats.get("photon_roots_culled", 0) - stats.get("shadow_rays_elided", 0),   # what the plain launch traces (value / rays_per_frame x this = traced rays per second)
                        "frames_per_step": world, "sec_per_frame": elapsed / args.steps,
                        "parallelism": "frames sharded over ranks, RGBA8 frames gathered to rank 0 over RCCL (gather of a step overlaps the next step's render; all gathers complete inside the timed region)" if world > 1 else "1 GPU"},
             "roofline": {"bound": "valu", "kernel": "trace_julia_kernel" if scene.desc.n_julias > 0 else "trace_kernel", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
