@@ -51,14 +51,14 @@ class HipRenderer:
         self.busy_events = None      # a list: render() then brackets its GPU work with event pairs (bench.py)
 
     def busy_seconds(self):
-        """GPU time of the render() calls (this renderer's and its twin's: render_units) since busy_events was set to a
+        """GPU time of the render() calls (this renderer's and its twins': render_units) since busy_events was set to a
         list — the union of their intervals, which overlap when two units are in flight; clears the list."""
         torch.cuda.synchronize()
         pairs = list(self.busy_events)
-        twin = getattr(self, "_twin", None)
-        if twin is not None and twin.busy_events:
-            pairs += twin.busy_events
-            twin.busy_events = []
+        for twin in getattr(self, "_twins", []):
+            if twin.busy_events:
+                pairs += twin.busy_events
+                twin.busy_events = []
         self.busy_events = []
         if not pairs:
             return 0.0
@@ -76,16 +76,18 @@ class HipRenderer:
 
     def lanes(self):
         """[(renderer, stream)] that render_units alternates its units over: this renderer and a twin (a second context on
-        the same GPU) on two side streams, so that the photon pass of one unit runs beside the trace kernel of the one
-        before — either leaves half of the GPU idle on frames of C5's size.  RT_DRIVER_OVERLAP=0: this renderer alone
-        on the current stream."""
+        the same GPU; RT_DRIVER_LANES - 1 of them) on side streams, so that the photon pass of one unit runs beside the
+        trace kernel of the one before — either leaves half of the GPU idle on frames of C5's size.
+        RT_DRIVER_OVERLAP=0: this renderer alone on the current stream."""
         if os.environ.get("RT_DRIVER_OVERLAP", "1") in ("", "0"):
             return [(self, None)]
-        if getattr(self, "_twin", None) is None:
-            self._twin = HipRenderer(self.device.index)
-            self._streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
-        self._twin.busy_events = [] if self.busy_events is not None else None
-        return [(self, self._streams[0]), (self._twin, self._streams[1])]
+        n = max(2, int(os.environ.get("RT_DRIVER_LANES", "2")))
+        if len(getattr(self, "_twins", [])) != n - 1:
+            self._twins = [HipRenderer(self.device.index) for _ in range(n - 1)]
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(n)]
+        for t in self._twins:
+            t.busy_events = [] if self.busy_events is not None else None
+        return [(self, self._streams[0])] + [(t, self._streams[k + 1]) for k, t in enumerate(self._twins)]
 
     def _photon_pass(self, enqueue, defer_check=False):
         """Enqueues a photon pass; if it outgrew the record buffer of the ordered sum (the library has resized it
@@ -297,8 +299,9 @@ def render_units(renderer, path, units, consume, payload=None):
                     consume(units[j], pics[r])
 
     lanes = renderer.lanes() if hasattr(renderer, "lanes") else [(renderer, None)]
-    two = len(lanes) == 2
-    raw = [None, None]        # two lanes: (picture, scene) of a unit whose photon pass has not been confirmed yet
+    n_lanes = len(lanes)
+    raw = [None] * n_lanes    # several lanes: (picture, scene) of the units whose photon pass has not been confirmed yet
+    unconfirmed = [0]         # the oldest of them
 
     def finish(i, out):
         """Round i's payload is on its way: hand it to the gather, after consuming round i-2 (whose buffers it takes)."""
@@ -313,21 +316,24 @@ def render_units(renderer, path, units, consume, payload=None):
                 gathered[b] = [torch.empty_like(out) for _ in range(world)]
             pending[b] = dist.gather(out, gathered[b] if rank == 0 else None, dst=0, async_op=True)
 
-    def confirm(i):
-        """Two lanes: unit i was enqueued a round ago with its photon pass unchecked (asking waits for the pass, and the
-        host has the next unit to upload meanwhile).  Confirms it, renders it again in the rare case that the pass outgrew
-        its record buffer, and sends the payload on."""
-        lane, side = lanes[i % 2]
-        pic, scene = raw[i % 2]
-        raw[i % 2] = None
-        main = torch.cuda.current_stream()
-        with torch.cuda.stream(side):
-            if not lane.photon_pass_ok():
-                pic = lane.render(scene)
-            out = payload(pic)
-        out.record_stream(main)
-        main.wait_stream(side)          # what follows on the main stream (gather, consume) sees the finished picture
-        finish(i, out)
+    def confirm_up_to(last):
+        """Several lanes: a unit is enqueued with its photon pass unchecked (asking waits for the pass, and the host has the
+        next units to upload meanwhile).  Confirms the units up to `last` in order, renders one again in the rare case
+        that its pass outgrew the record buffer, and sends the payloads on."""
+        while unconfirmed[0] <= last:
+            i = unconfirmed[0]
+            unconfirmed[0] += 1
+            lane, side = lanes[i % n_lanes]
+            pic, scene = raw[i % n_lanes]
+            raw[i % n_lanes] = None
+            main = torch.cuda.current_stream()
+            with torch.cuda.stream(side):
+                if not lane.photon_pass_ok():
+                    pic = lane.render(scene)
+                out = payload(pic)
+            out.record_stream(main)
+            main.wait_stream(side)          # what follows on the main stream (gather, consume) sees the finished picture
+            finish(i, out)
 
     with ThreadPoolExecutor(max_workers=1) as pool:
         nxt = pool.submit(load, 0) if rounds else None
@@ -336,20 +342,20 @@ def render_units(renderer, path, units, consume, payload=None):
             nxt = pool.submit(load, i + 1) if i + 1 < rounds else None
             if scene is None:
                 # a rank without a unit in the last round still takes part in the gather
-                if two and i >= 1 and raw[(i - 1) % 2] is not None:
-                    confirm(i - 1)
+                if n_lanes > 1:
+                    confirm_up_to(i - 1)
+                    unconfirmed[0] = i + 1
                 probe = capi.Scene(path, units[0][2])
                 finish(i, payload(torch.zeros((probe.width * probe.height, 4), dtype=torch.float32, device=device)))
-            elif two:
-                lane, side = lanes[i % 2]
+            elif n_lanes > 1:
+                lane, side = lanes[i % n_lanes]
                 with torch.cuda.stream(side):
-                    raw[i % 2] = (lane.render(scene, defer_check=True), scene)
-                if i >= 1 and raw[(i - 1) % 2] is not None:
-                    confirm(i - 1)              # round i is already on the GPU's queue
+                    raw[i % n_lanes] = (lane.render(scene, defer_check=True), scene)
+                confirm_up_to(i - (n_lanes - 1))      # the lane of unit i+1 becomes free; rounds up to i are on the GPU's queue
             else:
                 finish(i, payload(renderer.render(scene)))
-        if two and rounds >= 1 and raw[(rounds - 1) % 2] is not None:
-            confirm(rounds - 1)
+        if n_lanes > 1:
+            confirm_up_to(rounds - 1)
         for i in range(max(0, rounds - 2), rounds):
             consume_round(i)
 
