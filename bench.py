@@ -235,6 +235,7 @@ def split_measurements(which, renderer, ctx, capi, driver, world, rank, dev, rep
         return float(t.item())
 
     if "c4_tiles" in which:
+        progress("extra: c4_tiles")
         path = os.path.join(ROOT, "scenes", "examples3", "101_julia_shiny.xml")
         scene = capi.Scene(path, 0.0)
         rays = shared(count_rays(ctx, capi, path, [0.0])[0] if rank == 0 else 0)
@@ -253,6 +254,7 @@ def split_measurements(which, renderer, ctx, capi, driver, world, rank, dev, rep
     for key, name in (("c5_frames", "103_caustic_animation.xml"), ("c5mb8", "103_caustic_animation_mb8.xml")):
         if key not in which:
             continue
+        progress("extra: " + key)
         path = os.path.join(ROOT, "scenes", "examples3", name)
         info = capi.Scene(path, 0.0).info
         if info.sub_frames > 1:
@@ -294,6 +296,11 @@ def units_line(args, capi, driver, world, rank, local_rank, dev):
         dist.destroy_process_group()
 
 
+def progress(msg):
+    """Phase marker on stderr (stdout carries the one JSON line): a run that hangs says where."""
+    print("[bench rank %s] %s" % (os.environ.get("RANK", "0"), msg), file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,11 +320,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # RT_DIST_BACKEND=gloo: rehearsal of the N > 1 code on a box with fewer GPUs than ranks (the ranks share the GPUs
+    # there are, the collectives go through gloo); the numbers of such a run mean nothing
+    rehearsal = os.environ.get("RT_DIST_BACKEND", "nccl") == "gloo"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
+    progress("process group ready: world %d, device %s" % (world, dev))
 
     if args.workload == "c5mb":
         return units_line(args, capi, driver, world, rank, local_rank, dev)
@@ -346,6 +362,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     has_photons = scene.desc.photon_steps > 0
 
+    progress("counters launch")
     # ---- counters (untimed): rays and algorithmic flops of one step on this rank ------------------
     # Algorithmic work = the counts of the reference's formulation (nearest hit by a scan over all
     # objects, then shade once), which the counters of a BVH-less launch reproduce exactly
@@ -403,9 +420,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    progress("warm-up")
     for i in range(args.warmup):
         step(i)
     fence()
+    progress("timed steps")
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -416,6 +435,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    progress("timed steps done: %.3f ms per step" % (elapsed / args.steps * 1e3))
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
     ctx.launch_status()      # raises if the Julia kernel's watchdog abandoned the last launch
 

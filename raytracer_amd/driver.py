@@ -457,9 +457,14 @@ def main(argv=None):
     args = ap.parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("RT_DIST_BACKEND", "nccl") == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())      # rehearsal: more ranks than GPUs, collectives through gloo
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("RT_DIST_BACKEND", "nccl") == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     try:
         render_scene_file(HipRenderer(local_rank), args.scene, args.out)
     finally:
