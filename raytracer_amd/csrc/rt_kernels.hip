@@ -35,9 +35,6 @@ namespace rtd {
 #ifndef RT_JULIA_SHADER_PRIO
 #define RT_JULIA_SHADER_PRIO 0
 #endif
-#ifndef RT_JULIA_TAIL_RING
-#define RT_JULIA_TAIL_RING 0
-#endif
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 64
 #endif
@@ -1138,11 +1135,11 @@ enum CtxWord : int {
 };
 enum CtxFlag : unsigned { CF_KIND_MASK = 3u, CF_QACTIVE = 4u, CF_BLOCKED = 8u, CF_FOUND = 16u, CF_WAITING = 32u, CF_FRESH = 64u };
 enum JobStatus : unsigned { JOB_PENDING = 0u, JOB_MISS = 1u, JOB_HIT = 2u };
-enum RingId : int { R_MARCH = 0, R_NORMAL = 1, R_READY_T = 2, R_READY_S = 3, R_TAIL = 4, R_COUNT = 5 };
+enum RingId : int { R_MARCH = 0, R_NORMAL = 1, R_READY_T = 2, R_READY_S = 3, R_TAIL = 4, R_COUNT = RT_JULIA_TAIL_RING ? 5 : 4 };
 
 // Entry i of a ring lives at slot[i & (cap-1)] as ring_word(i, context id): one 16-bit store publishes the id and the
 // lap it belongs to (a slot holds the previous lap's word until its producer has written, so the lap number tells a
-// consumer that came first to wait; 16-bit words: five rings of 1024 entries and 896 contexts fill the CU's 160 KB).
+// consumer that came first to wait; 16-bit words: four rings of 1024 entries and 960 contexts fill the CU's 160 KB).
 struct JuliaRing {
     unsigned short slot[kJuliaQueueCap];
 };
@@ -1524,6 +1521,7 @@ RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n) {
     }
 }
 
+#if RT_JULIA_TAIL_RING
 // ---- marcher waves, march steps pooled through the TAIL ring (RT_JULIA_TAIL_RING) -----------------------------------
 // julia_marcher above takes the march steps of its own lanes, so a lane whose estimate is complete idles until enough
 // of its wave's lanes are (measured on C4: 37 of 64 lanes per step phase, a third of the estimator's lane slots
@@ -1720,6 +1718,7 @@ RT_DEV void julia_marcher_pooled(const DevScene& sc, PoolShared& sh, Counters& n
         beat(sh);
     }
 }
+#endif
 
 // ---- shader waves -------------------------------------------------------------------------------------------
 template <bool STATS>

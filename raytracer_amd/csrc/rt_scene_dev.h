@@ -238,8 +238,11 @@ constexpr uint32_t kDepositLongRun = 32;    // deposits into one texel from whic
 #ifndef RT_JULIA_MARCHERS
 #define RT_JULIA_MARCHERS 10
 #endif
+#ifndef RT_JULIA_TAIL_RING
+#define RT_JULIA_TAIL_RING 0        // 1: march steps pooled through a fifth ring (rt_kernels.hip: julia_marcher_pooled; measured slower)
+#endif
 #ifndef RT_JULIA_POOL
-#define RT_JULIA_POOL 896
+#define RT_JULIA_POOL (RT_JULIA_TAIL_RING ? 896 : 960)     // with the rings: all the LDS of a CU
 #endif
 constexpr int kJuliaWaves = RT_JULIA_WAVES;              // per workgroup, a multiple of 4 (waves per SIMD = kJuliaWaves / 4)
 constexpr int kJuliaMarcherWaves = RT_JULIA_MARCHERS;    // the rest are shader waves
