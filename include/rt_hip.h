@@ -315,6 +315,11 @@ int rt_kat_fresnel(rt_ctx* ctx, const float* records, uint32_t n, float* out);
 /* Raw counter words of the last counters-enabled launch, incl. the wave-scheduler diagnostics
  * (developer tool; returns the number of words). */
 int rt_debug_counters(rt_ctx* ctx, uint64_t* out, uint32_t cap);
+/* The host builder of the BVH of short triangle runs (surface-area tree, no counterpart in the reference: it tests every
+ * object for every ray, src/raytracer.cpp:126), without a device: n triangles of 9 floats (p0, e1, e2) in, n-1 records
+ * of 16 words out (rt_scene_dev.h: DevBvhPair — boxes of both children, child words with bit 31 = leaf | triangle index).
+ * Host-only (tests/test_bvh_host.py checks the tree's invariants on the CPU). */
+int rt_debug_bvh_host(const float* triangles, uint32_t n, uint32_t* records_out);
 
 #ifdef __cplusplus
 }

@@ -1445,6 +1445,23 @@ int rt_debug_counters(rt_ctx* ctx, uint64_t* out, uint32_t cap) {
     return C_COUNT;
 }
 
+// The host BVH builder on caller-supplied triangles (no device involved).
+int rt_debug_bvh_host(const float* triangles, uint32_t n, uint32_t* records_out) {
+    if (triangles == nullptr || records_out == nullptr || n < 2 || n > (1u << 24)) return RT_ERR_INVALID_ARGUMENT;
+    std::vector<DevTriTest> tris(n);
+    for (uint32_t i = 0; i < n; i++) {
+        for (int c = 0; c < 3; c++) {
+            tris[i].p0[c] = triangles[i * 9 + c];
+            tris[i].e1[c] = triangles[i * 9 + 3 + c];
+            tris[i].e2[c] = triangles[i * 9 + 6 + c];
+            tris[i].pad[c] = 0.0f;
+        }
+    }
+    static_assert(sizeof(DevBvhPair) == 16 * sizeof(uint32_t), "DevBvhPair");
+    build_triangle_bvh_host(tris.data(), 0, n, reinterpret_cast<DevBvhPair*>(records_out));
+    return RT_OK;
+}
+
 // ---- known-answer hooks (tests only; declared in include/rt_hip.h under "test hooks") ----------------
 
 // Object::intersect (reference src/objects.h:124-126) of scene object object_index[i] for n rays given
