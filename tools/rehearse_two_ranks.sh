@@ -1,7 +1,9 @@
 #!/bin/bash
 # developer tool (GPU box with ONE GPU): the torch driver with two ranks sharing the GPU, collectives through gloo
 # (RT_DIST_BACKEND=gloo), on small variants of the caustic animation (plain and motion blur) and a Julia still: the files must
-# be the single-process ones, byte for byte.  Two processes on one GPU take turns at it, so this is slow for what it renders.
+# be the single-process ones, byte for byte.  Two processes on one GPU take turns at it, so this is slow for what it renders
+# (and bench.py --gpus 2 with its full-size frames is not a usable rehearsal: two persistent grids sharing the GPU took 1 s per
+# 1.8 ms step when they ran at all).
 set -e
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/rehearse; mkdir -p $OUT
