@@ -8,7 +8,11 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 HOSTFLAGS = -O2 -std=c++17 -pthread -ffp-contract=off -fPIC -Wall -Wextra
 HOST_SRCS = raytracer_amd/host/scene_loader.cpp raytracer_amd/host/png_io.cpp raytracer_amd/host/host_capi.cpp
 HOST_HDRS = $(wildcard raytracer_amd/host/*.h) include/rt_hip.h
-HIPFLAGS  = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall
+# -fno-slp-vectorize: the SLP vectoriser packs the scalar float code of the object loop and the shading code into
+# v_pk_* instructions on 64-bit register pairs behind v_mov shuffles; without it trace_kernel needs 129 VGPRs
+# instead of 155, its dense variant and photon_kernel spill nothing, trace_julia_kernel spills 11 VGPRs instead of 68
+# [MI355X: C3 8.95 -> 7.92 ms, C5 render 0.67 -> 0.58, C2 1.75 -> 1.70].  Hand-packed code (the Julia estimator) is inline asm.
+HIPFLAGS  = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall
 
 all: host hip cli oracle
 

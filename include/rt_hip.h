@@ -170,8 +170,10 @@ typedef struct rt_stats {
     uint64_t texture_lookups;
     uint64_t bvh_node_visits;
     double   kernel_ms;             /* device time of the last call's kernels (HIP events) */
-    uint64_t shadow_rays_elided;    /* of shadow_rays: towards lights that can only add +-0 (surface with kd == ks == 0); a launch
-                                       without counters does not trace them (RT_OPT_ELIDE_UNLIT_SHADOWS), a counters launch does */
+    uint64_t shadow_rays_elided;    /* of shadow_rays: towards lights whose Phong terms can only be +-0 at that point (diffuse term:
+                                       kd == 0 or the light is behind the surface; specular term: ks == 0 or the mirrored light
+                                       direction points away from the viewer); a launch without counters does not trace them
+                                       (RT_OPT_ELIDE_UNLIT_SHADOWS), a counters launch does */
     uint64_t photon_roots_culled;   /* of the photon pass's roots: light rays that pass every refracting or reflecting object by and
                                        so can leave nothing (RT_OPT_CULL_PHOTON_ROOTS); counted by a counters launch, which traces them */
 } rt_stats;
@@ -204,11 +206,14 @@ enum {
                                    at least 262144; grows by itself as described above */
     RT_OPT_DEBUG_FORCE_ABORT = 6, /* test hook, 0/1: the Julia kernel's first workgroup raises its watchdog flag at once, as a wave
                                    stuck on the job queues would: the launch is then reported as abandoned (RT_ERR_HIP) */
-    RT_OPT_ELIDE_UNLIT_SHADOWS = 7, /* 1 (default): a shadow ray towards a light that can only add +-0 to the radiance — the surface
-                                   has kd == 0 and ks == 0 (mirror, clear glass) and no factor is infinite or NaN — is not
-                                   traced (the reference casts it and multiplies the result by zero, src/raytracer.cpp:214-235);
-                                   same picture bit for bit.  rt_stats.shadow_rays still counts it, shadow_rays_elided says how
-                                   many.  0: trace every shadow ray. */
+    RT_OPT_ELIDE_UNLIT_SHADOWS = 7, /* 1 (default): a shadow ray towards a light that can only add +-0 to the radiance is not traced
+                                   (the reference casts it and multiplies the result by zero, src/raytracer.cpp:214-235).  That is
+                                   the case when BOTH Phong terms of that light vanish at the point: the diffuse one because
+                                   kd == 0 or n.l <= 0 (light behind the surface), the specular one because ks == 0 or r.v <= 0
+                                   with exponent > 0 (pow(0, e) = 0) — the back of every object as seen from the light, all of a
+                                   mirror or of clear glass — and no factor is infinite or NaN (material, lights, point and
+                                   normal are checked).  Same picture bit for bit.  rt_stats.shadow_rays still counts such
+                                   rays, shadow_rays_elided says how many.  0: trace every shadow ray. */
     RT_OPT_CULL_PHOTON_ROOTS = 8   /* 1 (default): a root of the photon pass (src/photonmap.cpp:38-58) whose ray misses the box around
                                    every object that refracts or reflects light rays is not traced: the reference deposits a light
                                    ray only after such a bounce (src/photonmap.cpp:79-83), so these roots leave nothing.  Same photon

@@ -131,11 +131,8 @@ def test_intersectors_on_seeded_rays_against_oracle(hip_ctx):
         assert hit == (out[i, 0] != 0), i
         if hit:
             hits += 1
-            if sc.desc.objects[int(objs[i])].kind == capi.RT_OBJ_SPHERE:
-                assert np.array_equal(out[i, 1:8].view(np.uint32), want[:7].view(np.uint32)), i
-                assert np.all(np.abs(out[i, 8:12] - want[7:]) <= 3e-7), i
-            else:
-                assert np.array_equal(out[i, 1:12].view(np.uint32), want.view(np.uint32)), i
+            # sphere uv included: rt_libm.h restates glibc's asinf/atan2f, so no tolerance is left
+            assert np.array_equal(out[i, 1:12].view(np.uint32), want.view(np.uint32)), i
     assert hits > 300
 
 
@@ -582,7 +579,8 @@ def test_cli_renders_the_caustic_animation_like_the_reference(tmp_path):
         img, n = capi.png_read(out, frame)
         gold, m = capi.png_read(golden_path("c5_caustic_animation.png"), frame)
         assert n == m == 20
-        assert_north_star(img, gold, "cli frame %d" % frame)
+        d = assert_north_star(img, gold, "cli frame %d" % frame)
+        assert d["max"] == 0, (frame, d)   # ordered photon sums: the reference's file, pixel for pixel
 
 
 def test_driver_motion_blur_like_the_reference(tmp_path):
@@ -742,10 +740,9 @@ def test_bvh_forced_on_the_configured_scenes():
         img, _ = ctx.render()
         ph = oracle_lib.Photons(sc) if sc.desc.photon_steps > 0 else None
         ref, _ = oracle_lib.render(sc, ph, threads=16)
-        if ph is None:
-            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), rel
-        else:
-            assert np.allclose(img, ref, rtol=1e-5, atol=1e-7), rel
+        # photon scenes too: the deposits are summed in the reference's order
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), rel
+        assert pst.kernel_ms >= 0.0
     ctx.close()
 
 

@@ -4,7 +4,7 @@
 set -e
 NAME=$1; shift
 mkdir -p ab build/ab_$NAME
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall"
 for f in rt_api rt_kernels; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c -o build/ab_$NAME/$f.o raytracer_amd/csrc/$f.hip &
 done
