@@ -127,7 +127,18 @@ def cpu_baseline(scene, n_rays_frame):
                 step, (cam.height + step - 1) // step, reps, " + serial photon pass" if photons else "", dt, cores)}
 
 
-def cpu_reference(scene_path, n_rays_frame, still_at=None):
+def ofast_ratio(key):
+    """SURVEY 8d's calibration ratio: how much faster the reference built with its author's flags (-Ofast -flto -march=native)
+    is than the O-strict build timed here, per config (profiles/cpu_reference_ofast_ratio.json, tools/ofast_ratio.py)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "cpu_reference_ofast_ratio.json")) as f:
+            rec = json.load(f)["configs"].get(key)
+        return {"ratio": rec["ratio"], "strict_s": rec["strict_s"], "ofast_s": rec["ofast_s"]} if rec else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def cpu_reference(scene_path, n_rays_frame, still_at=None, ratio_key=None):
     """The reference's own program (oracle/_ref/raytracer_ostrict: its unmodified sources compiled by
     oracle/Makefile, g++ -O2) on the same scene file with threads = host cores; time = its own
     'Finished in' line (trace + PNG encode, src/main.cpp:23-35).  `still_at` renders one frame of an animated
@@ -152,17 +163,28 @@ def cpu_reference(scene_path, n_rays_frame, still_at=None):
             path = os.path.join(tmp, "bench_scene.xml")
             with open(path, "w") as f:
                 f.write(xml)
+            t0 = time.perf_counter()
             out = subprocess.run([exe, path, os.path.join(tmp, "out.png")], capture_output=True, text=True, timeout=240).stdout
+            wall = time.perf_counter() - t0
         m = re.search(r"Finished in ([0-9.eE+-]+)\s*s", out)
         if not m:
             return None
         sec = float(m.group(1))
+        timer = "its own 'Finished in' timer = %.2f s (trace + PNG encode)" % sec
+        if still_at is not None:
+            # a still's timer starts AFTER the photon pass (src/main.cpp:18-23): the process's wall clock covers it
+            # (+ scene load, milliseconds), as the timers of the reference's animation loops do (src/main.cpp:82-111)
+            timer = "wall clock of the process = %.2f s (scene load + serial photon pass + trace + PNG encode; its 'Finished in' timer, which excludes the photon pass, says %.2f s)" % (wall, sec)
+            sec = wall
+        ratio = ofast_ratio(ratio_key)
         return {"value": n_rays_frame / sec, "unit": "rays/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "reference",
-                "sec_per_frame": sec,
-                "sample": "oracle/_ref/raytracer_ostrict (reference sources, g++ -O2 -pthread; the author's -Ofast build is not "
-                          "bit-reproducible and is not used), whole frame%s, threads=%d, its own 'Finished in' timer = %.2f s "
-                          "(%strace + PNG encode); rays = the nearest-hit formulation's count" % (
-                              "" if still_at is None else " at <still time=%r>" % still_at, cores, sec, "photon pass + " if still_at is not None else "")}
+                "sec_per_frame": sec, "ofast_ratio": ratio,
+                "sample": "oracle/_ref/raytracer_ostrict (reference sources, g++ -O2 -pthread), whole frame%s, threads=%d, %s; rays = the "
+                          "nearest-hit formulation's count.  The author's shipping flags (-Ofast -flto -march=native, host-specific, so that "
+                          "build stays off this box) make the reference %s faster on this config (profiles/cpu_reference_ofast_ratio.json: both "
+                          "builds timed on the build container's 8 vCPUs, tools/ofast_ratio.py): divide the GPU/CPU ratio by that" % (
+                              "" if still_at is None else " at <still time=%r>" % still_at, cores, timer,
+                              "%.2fx" % ratio["ratio"] if ratio else "1.0-1.2x (no calibration file)")}
     except Exception:   # noqa: BLE001 - a missing or failing reference binary must not break the bench line
         return None
 
@@ -170,11 +192,12 @@ def cpu_reference(scene_path, n_rays_frame, still_at=None):
 # ------------------------------------------------------------------------- the north star's splits, through the driver
 
 def count_rays(ctx, capi, path, times):
-    """(rays, algorithmic flops) of the units at `times` from counters-enabled launches; rays = primary + secondary +
-    shadow + photon segments."""
+    """(rays, algorithmic flops, rays not traced) of the units at `times` from counters-enabled launches; rays = primary +
+    secondary + shadow + photon segments of the reference's formulation; not traced = the photon roots dropped before the
+    pass and the shadow rays that can only add +-0, which a plain launch skips."""
     import torch
     ctx.set_option(capi.RT_OPT_COLLECT_STATS, 1)
-    total, flops = 0, 0.0
+    total, flops, skipped = 0, 0.0, {"photon_roots_culled": 0, "shadow_rays_elided": 0}
     for t in times:
         scene = capi.Scene(path, float(t))
         ctx.upload(scene)
@@ -185,8 +208,11 @@ def count_rays(ctx, capi, path, times):
         r = ctx.fetch_stats().as_dict()
         total += r["primary_rays"] + r["secondary_rays"] + r["shadow_rays"] + d.get("photon_segments", 0)
         flops += algorithmic_flops({k: v + d.get(k, 0) for k, v in r.items() if k != "kernel_ms"})
+        # rays of the reference's formulation that the plain launches do not trace
+        skipped["photon_roots_culled"] += d.get("photon_roots_culled", 0)
+        skipped["shadow_rays_elided"] += r.get("shadow_rays_elided", 0)
     ctx.set_option(capi.RT_OPT_COLLECT_STATS, 0)
-    return total, flops
+    return total, flops, skipped
 
 
 def timed_job(job, renderer, reps, warmup, world, dev):
@@ -238,7 +264,9 @@ def split_measurements(which, renderer, ctx, capi, driver, world, rank, dev, rep
         progress("extra: c4_tiles")
         path = os.path.join(ROOT, "scenes", "examples3", "101_julia_shiny.xml")
         scene = capi.Scene(path, 0.0)
-        rays = shared(count_rays(ctx, capi, path, [0.0])[0] if rank == 0 else 0)
+        rays, _flops, skipped = count_rays(ctx, capi, path, [0.0]) if rank == 0 else (0, 0.0, {})
+        rays, traced = shared(rays), shared(rays - sum(skipped.values()))
+        elided, culled = shared(skipped.get("shadow_rays_elided", 0)), shared(skipped.get("photon_roots_culled", 0))
         host = driver.HostFrames(dev)
 
         def job():
@@ -250,7 +278,82 @@ def split_measurements(which, renderer, ctx, capi, driver, world, rank, dev, rep
         wall, busy = timed_job(job, renderer, reps, warmup, world, dev)
         out["c4_tiles"] = {"scene": "examples3/101_julia_shiny.xml", "split": "8-row bands interleaved over %d rank(s), float bands gathered to rank 0" % world,
                            "scaling": "strong", "frames": reps, "sec_per_frame": wall / reps, "rays_per_frame": rays,
-                           "rays_per_s": rays * reps / wall, "gpu_busy_frac_per_rank": busy}
+                           "rays_per_s": rays * reps / wall, "rays_traced_per_frame": traced, "rays_traced_per_s": traced * reps / wall,
+                           "shadow_rays_elided_per_frame": elided, "photon_roots_culled_per_frame": culled, "gpu_busy_frac_per_rank": busy}
+    if "c4_tiles" in which and world == 1:
+        # What bounds C4's 8-GPU band split, measured on this one GPU: the kernel time of each rank's share (bands r, r + 8,
+        # r + 16 ... of 8 rows).  The slowest share is the frame time of an 8-GPU run (plus the 9.2 MB float gather).
+        progress("extra: c4 band eighths")
+        path = os.path.join(ROOT, "scenes", "examples3", "101_julia_shiny.xml")
+        scene = capi.Scene(path, 0.0)
+        ctx.upload(scene)
+        stream = torch.cuda.current_stream().cuda_stream
+        eighth_ms = []
+        for r in range(8):
+            bands = capi.Bands(driver.BAND_ROWS, r, 8)
+            buf = torch.empty((ctx.pixel_count(bands), 4), dtype=torch.float32, device=dev)
+            ms = []
+            for rep in range(1 + reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                ctx.render_device(buf.data_ptr(), stream, bands)
+                b.record()
+                ctx.launch_status()
+                torch.cuda.synchronize()
+                if rep > 0:
+                    ms.append(a.elapsed_time(b))
+            eighth_ms.append(round(float(np.mean(ms)), 4))
+        whole_ms = out["c4_tiles"]["sec_per_frame"] * 1e3
+        out["c4_band_eighth_ms"] = eighth_ms
+        out["c4_band_eighth"] = {"max_ms": max(eighth_ms), "mean_ms": round(float(np.mean(eighth_ms)), 4), "whole_frame_ms": round(whole_ms, 4),
+                                 "implied_8gpu_speedup_ceiling": round(whole_ms / max(eighth_ms), 3),
+                                 "note": "kernel time of rt_bands{8, r, 8} for r = 0..7 on ONE GPU (events on the launch stream): what each of 8 ranks would "
+                                         "render; whole frame / slowest share = the strong-scaling ceiling of the band split before the gather"}
+    if "c5_frames" in which and world == 1:
+        # What bounds C5's 8-GPU frame split: rank 0's host time per gathered unit (every rank renders, rank 0 alone
+        # consumes).  World 1 with the collective forced on (RT_DRIVER_FORCE_GATHER=1) runs rank 0's consume loop as an
+        # 8-GPU run would; at 8 GPUs it must stay below an eighth of a unit's GPU time.
+        progress("extra: c5 rank-0 host cost per unit")
+        path = os.path.join(ROOT, "scenes", "examples3", "103_caustic_animation.xml")
+        started_group = False
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29655")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            started_group = True
+        os.environ["RT_DRIVER_FORCE_GATHER"] = "1"
+        consume_s = [0.0, 0]
+        real_render_units = driver.render_units
+
+        def timed_render_units(renderer_, path_, units, consume, payload=None):
+            def timed_consume(u, pic):
+                t0 = time.perf_counter()
+                consume(u, pic)
+                consume_s[0] += time.perf_counter() - t0
+                consume_s[1] += 1
+            return real_render_units(renderer_, path_, units, timed_consume, payload)
+        driver.render_units = timed_render_units
+        try:
+            driver.render_frames(renderer, path)      # warm-up
+            consume_s[0], consume_s[1] = 0.0, 0
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                driver.render_frames(renderer, path)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+        finally:
+            driver.render_units = real_render_units
+            os.environ.pop("RT_DRIVER_FORCE_GATHER", None)
+            if started_group:
+                dist.destroy_process_group()
+        units_done = max(1, consume_s[1])
+        out["c5_rank0_host_us_per_unit"] = round(consume_s[0] / units_done * 1e6, 2)
+        out["c5_rank0_gather"] = {"consume_us_per_unit": round(consume_s[0] / units_done * 1e6, 2), "units": units_done,
+                                  "loop_us_per_unit_world1": round(wall / units_done * 1e6, 2),
+                                  "note": "one-rank RCCL group with the gather forced on: host time of rank 0's consume call per gathered unit "
+                                          "(wait for the gather + hand the RGBA8 frame to the download stream), and the whole loop's wall time per unit "
+                                          "at world 1 (parse + upload + enqueue + gather + consume on one rank)"}
     for key, name in (("c5_frames", "103_caustic_animation.xml"), ("c5mb8", "103_caustic_animation_mb8.xml")):
         if key not in which:
             continue
@@ -261,13 +364,16 @@ def split_measurements(which, renderer, ctx, capi, driver, world, rank, dev, rep
             times = [u[2] for u in driver.motion_blur_units(path, info)]
         else:
             times = [float(f32(f) / f32(info.frames - 1)) for f in range(info.frames)]
-        rays, flops = count_rays(ctx, capi, path, times) if rank == 0 else (0, 0.0)
-        rays, flops = shared(rays), shared(flops)
+        rays, flops, skipped = count_rays(ctx, capi, path, times) if rank == 0 else (0, 0.0, {})
+        rays, flops, traced = shared(rays), shared(flops), shared(rays - sum(skipped.values()))
+        elided, culled = shared(skipped.get("shadow_rays_elided", 0)), shared(skipped.get("photon_roots_culled", 0))
         wall, busy = timed_job(lambda: driver.render_frames(renderer, path), renderer, reps, warmup, world, dev)
         out[key] = {"scene": "examples3/" + name, "split": "%d units round-robin over %d rank(s), pipelined gathers to rank 0" % (len(times), world),
                     "scaling": "strong", "repetitions": reps, "units": len(times), "frames": info.frames,
                     "units_per_s": len(times) * reps / wall, "sec_per_frame": wall / reps / info.frames, "sec_per_file": wall / reps,
-                    "rays_per_file": rays, "flops_per_file": flops, "rays_per_s": rays * reps / wall, "gpu_busy_frac_per_rank": busy}
+                    "rays_per_file": rays, "flops_per_file": flops, "rays_per_s": rays * reps / wall,
+                    "rays_traced_per_file": traced, "rays_traced_per_s": traced * reps / wall,
+                    "shadow_rays_elided_per_file": elided, "photon_roots_culled_per_file": culled, "gpu_busy_frac_per_rank": busy}
     return out
 
 
@@ -277,12 +383,15 @@ def units_line(args, capi, driver, world, rank, local_rank, dev):
     renderer = driver.HipRenderer(local_rank)
     res = split_measurements(("c5mb8",), renderer, renderer.ctx, capi, driver, world, rank, dev, args.steps, args.warmup)["c5mb8"]
     if rank == 0:
-        line = {"metric": "rays/sec", "value": res["rays_per_s"], "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        line = {"metric": "rays/sec", "value": res["rays_per_s"], "unit": "rays/s", "rays_traced_per_s": res["rays_traced_per_s"],
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": res["sec_per_file"] * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                 "data": "scene-file",
                 "config": {"workload": "C5 examples3/103_caustic_animation_mb8.xml: 20 frames x 8 motion-blur sub-frames = 160 units (photon pass + render each)",
                            "scene": res["scene"], "units": res["units"], "units_per_s": res["units_per_s"], "sec_per_frame": res["sec_per_frame"],
-                           "rays_per_file": res["rays_per_file"], "gpu_busy_frac_per_rank": res["gpu_busy_frac_per_rank"], "parallelism": res["split"]},
+                           "rays_per_file": res["rays_per_file"], "rays_traced_per_file": res["rays_traced_per_file"],
+                           "shadow_rays_elided_per_file": res["shadow_rays_elided_per_file"], "photon_roots_culled_per_file": res["photon_roots_culled_per_file"],
+                           "gpu_busy_frac_per_rank": res["gpu_busy_frac_per_rank"], "parallelism": res["split"]},
                 "roofline": None}
         busy_s = sum(res["gpu_busy_frac_per_rank"]) * res["sec_per_file"] * args.steps      # GPU seconds of all ranks
         achieved = res["flops_per_file"] * args.steps / busy_s / 1e12
@@ -451,14 +560,18 @@ def main():
     if rank == 0:
         value = rays_per_step * world * args.steps / elapsed
         achieved = flops_per_step / (kernel_ms * 1e-3) / 1e12
+        rays_traced = rays_per_step - stats.get("photon_roots_culled", 0) - stats.get("shadow_rays_elided", 0)
         line = {
-            "metric": "rays/sec", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "metric": "rays/sec", "value": value, "unit": "rays/s",
+            # `value` counts the rays of the reference's formulation (what rays/s is quoted on); this one only those the launch traces
+            "rays_traced_per_s": rays_traced * world * args.steps / elapsed,
+            "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "scene-file",
             "config": {"workload": label, "scene": rel, "t": t, "rays_per_frame": rays_per_step,
                        "photon_roots_culled_per_frame": stats.get("photon_roots_culled", 0),   # of the photon pass's roots, counted in rays_per_frame, dropped before the pass: DESIGN.md 4.6
                        "shadow_rays_elided_per_frame": stats.get("shadow_rays_elided", 0),   # counted in rays_per_frame (rays of the reference's formulation), not traced: DESIGN.md 4.4
-                       "rays_traced_per_frame": rays_per_step - stats.get("photon_roots_culled", 0) - stats.get("shadow_rays_elided", 0),   # what the plain launch traces (value / rays_per_frame x this = traced rays per second)
+                       "rays_traced_per_frame": rays_traced,   # what the plain launch traces
                        "frames_per_step": world, "sec_per_frame": elapsed / args.steps,
                        "parallelism": "frames sharded over ranks, RGBA8 frames gathered to rank 0 over RCCL (gather of a step overlaps the next step's render; all gathers complete inside the timed region)" if world > 1 else "1 GPU"},
             "roofline": {"bound": "valu", "kernel": "trace_julia_kernel" if scene.desc.n_julias > 0 else "trace_kernel", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
@@ -470,13 +583,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene, rays_per_step)
             if args.workload != "mesh":
-                ref = cpu_reference(os.path.join(ROOT, "scenes", rel), rays_per_step, still_at=t if has_photons else None)
+                ref = cpu_reference(os.path.join(ROOT, "scenes", rel), rays_per_step, still_at=t if has_photons else None, ratio_key=args.workload)
                 if ref is not None:
                     line["cpu_reference"] = ref
         if extra is not None:
             if world == 1 and not args.no_cpu_baseline:
                 c5 = os.path.join(ROOT, "scenes", "examples3", "103_caustic_animation.xml")
-                ref = cpu_reference(c5, extra["c5_frames"]["rays_per_file"] / extra["c5_frames"]["frames"], still_at=0.5)
+                ref = cpu_reference(c5, extra["c5_frames"]["rays_per_file"] / extra["c5_frames"]["frames"], still_at=0.5, ratio_key="c5")
                 if ref is not None:
                     extra["c5_cpu_reference"] = ref
             line["extra"] = extra

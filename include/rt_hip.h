@@ -264,7 +264,10 @@ int rt_fetch_stats(rt_ctx* ctx, rt_stats* out);
  * do not fit, fewer workgroups are launched (slower, same result).  RT_ERR_LIMIT with a message that names the
  * sizes when the sample buffer, or the stacks of a single workgroup, do not fit.  Counters are not collected
  * (RT_OPT_COLLECT_STATS is ignored).  ALL calls on one GPU share that GPU's workspace: two calls that overlap in
- * time on one GPU (two streams, two contexts, two threads) race.  rt_launch_status applies as for rt_render_device. */
+ * time on one GPU (two streams, two contexts, two threads) race.  rt_launch_status applies as for rt_render_device:
+ * the watchdog word of the fixed workspace stays set until a context has seen it there, so an abandoned launch is
+ * reported even when further launches of either entry point were enqueued before the status was asked for (and,
+ * the word being shared like the rest of the workspace, by every context whose no-alloc Julia launch ran before then). */
 #ifndef RT_NOALLOC_SCRATCH_BYTES
 #define RT_NOALLOC_SCRATCH_BYTES (32u << 20)
 #endif

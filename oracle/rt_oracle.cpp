@@ -238,6 +238,20 @@ V3 julia_normal(const rt_julia& j, Quat pos, float diff, Counters& n) {
     return normalized({dist[0] - dist[1], dist[2] - dist[3], dist[4] - dist[5]});
 }
 
+// Diagnostic only (oracle_march_histogram): marches by length.  A march is a chain of dependent steps, so the longest
+// ones bound the latency of a frame whatever the machine's throughput.
+std::atomic<uint64_t> g_march_hist[16];        // marches of 2^(k-1) < steps <= 2^k
+std::atomic<uint64_t> g_march_hist_steps[16];  // ... their steps
+std::atomic<uint64_t> g_march_longest_iterations{0};   // estimator iterations of the march with the most of them
+void note_march(uint32_t steps, uint64_t iterations) {
+    int k = 0;
+    while ((1u << k) < steps && k < 15) k++;
+    g_march_hist[k].fetch_add(1, std::memory_order_relaxed);
+    g_march_hist_steps[k].fetch_add(steps, std::memory_order_relaxed);
+    uint64_t seen = g_march_longest_iterations.load(std::memory_order_relaxed);
+    while (iterations > seen && !g_march_longest_iterations.compare_exchange_weak(seen, iterations, std::memory_order_relaxed)) {}
+}
+
 bool julia_intersect(const rt_julia& j, const Ray& ray, float max_distance, Hit* out, Counters& n) {
     n.julia_queries++;
     const V3 position = v3(j.position);
@@ -254,8 +268,11 @@ bool julia_intersect(const rt_julia& j, const Ray& ray, float max_distance, Hit*
         p = add(p, mul(d, distance));
     }
     float distance = 0.0f;
+    uint32_t steps = 0;
+    const uint64_t iterations_before = n.julia_de_iterations;
     for (uint32_t i = 0; i < JULIA_SEARCH_ITERATIONS; i++) {
         n.julia_steps++;
+        steps++;
         distance = julia_distance(j, {p.x, p.y, p.z, j.cut_plane}, JULIA_DISTANCE_ITERATIONS, n);
         if (i == 0 && distance < JULIA_CONVERGENCE_LIMIT) {
             distance = 100 * JULIA_CONVERGENCE_LIMIT;
@@ -264,6 +281,7 @@ bool julia_intersect(const rt_julia& j, const Ray& ray, float max_distance, Hit*
         }
         p = add(p, mul(d, distance));
     }
+    note_march(steps, n.julia_de_iterations - iterations_before);
     if (distance >= JULIA_CONVERGENCE_LIMIT) return false;
     V3 normal = julia_normal(j, {p.x, p.y, p.z, j.cut_plane}, JULIA_GRADIENT_DIFF, n);
     if (dot(normal, d) > 0.0f) normal = mul(normal, -1.0f);
@@ -713,6 +731,25 @@ void oracle_photon_get(const oracle_photons* p, uint32_t object_index, float* rg
 // ≙ RayTracer::raytrace: renders rows [row_begin, row_end) stepping by row_step, each into its place
 // of the full width*height RGBA float image `rgba_out` (other rows untouched).  `threads` workers
 // pull rows from an atomic counter like the reference (src/raytracer.cpp:31-53).
+void oracle_camera_ray(const rt_scene_desc* sc, uint32_t x, uint32_t y, uint32_t sx, uint32_t sy, float* out);
+// Diagnostic: when set, oracle_render_rows writes every pixel's Julia march steps (all of its samples' rays) there.
+static float* g_cost_map = nullptr;
+void oracle_set_cost_map(float* per_pixel) { g_cost_map = per_pixel; }
+// Diagnostic: Julia march steps of the primary ray through the centre of pixel (x, y) alone (nearest-hit query only).
+uint64_t oracle_probe_steps(const rt_scene_desc* sc, uint32_t x, uint32_t y) {
+    float r[6];
+    rt_scene_desc one = *sc;
+    one.camera.supersampling = 1;
+    oracle_camera_ray(&one, x, y, 0, 0, r);
+    Tracer tr{*sc, nullptr, {}};
+    const Ray ray = make_ray(v3(r), v3(r + 3));
+    for (uint32_t o = 0; o < sc->n_objects; o++) {
+        Hit h{};
+        if (sc->objects[o].kind == RT_OBJ_JULIA) (void)tr.intersect(o, ray, INFINITE_F, &h);
+    }
+    return tr.n.julia_steps;
+}
+
 void oracle_render_rows(const rt_scene_desc* sc, const oracle_photons* photons, uint32_t row_begin,
                         uint32_t row_end, uint32_t row_step, int threads, float* rgba_out, rt_stats* stats) {
     const CameraFrame frame = camera_frame(sc->camera);
@@ -727,7 +764,9 @@ void oracle_render_rows(const rt_scene_desc* sc, const oracle_photons* photons, 
         while ((i = next.fetch_add(1, std::memory_order_relaxed)) < n_rows) {
             const uint32_t y = row_begin + i * row_step;
             for (uint32_t x = 0; x < sc->camera.width; x++) {
+                const uint64_t steps_before = tr.n.julia_steps;
                 const Col c = render_pixel(tr, frame, x, y);
+                if (g_cost_map != nullptr) g_cost_map[size_t(y) * sc->camera.width + x] = static_cast<float>(tr.n.julia_steps - steps_before);
                 float* px = rgba_out + (size_t(y) * sc->camera.width + x) * 4;
                 px[0] = c.r;
                 px[1] = c.g;
@@ -816,6 +855,16 @@ void oracle_photon_scan(float steps, uint32_t cap, float* phi_out, uint32_t* n_p
     }
     *n_phi = np;
     *n_theta = nt;
+}
+
+// Diagnostic: marches by length since the last call (k: 2^(k-1) < steps <= 2^k): counts[16], steps[16], and the most
+// estimator iterations any single march made.  Not part of any parity check.
+void oracle_march_histogram(uint64_t* counts, uint64_t* steps, uint64_t* longest_iterations) {
+    for (int k = 0; k < 16; k++) {
+        counts[k] = g_march_hist[k].exchange(0);
+        steps[k] = g_march_hist_steps[k].exchange(0);
+    }
+    *longest_iterations = g_march_longest_iterations.exchange(0);
 }
 
 }  // extern "C"

@@ -292,6 +292,7 @@ class Context:
             raise RtError("rt_create failed (%d): %s" % (rc, self._lib.rt_last_error(None).decode()))
         self.scene = None
         self.ordered_photons = True      # RT_OPT_PHOTON_ORDER as last set through set_option
+        self.options = {}                # every option set through set_option, in order (driver.HipRenderer.lanes replays them)
 
     def _check(self, rc, what):
         if rc != 0:
@@ -303,6 +304,8 @@ class Context:
 
     def set_option(self, option, value):
         self._check(self._lib.rt_set_option(self._ctx, option, value), "rt_set_option")
+        self.options.pop(option, None)
+        self.options[option] = value
         if option == RT_OPT_PHOTON_ORDER:
             self.ordered_photons = bool(value)
 

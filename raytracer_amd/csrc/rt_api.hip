@@ -141,12 +141,13 @@ struct rt_ctx {
     unsigned char* h_out = nullptr;        // pinned block the synchronous entry points copy their pictures through
     size_t h_out_bytes = 0;
     unsigned long long* d_queue = nullptr;      // [0] = queue head, [1] = watchdog flag of trace_julia_kernel (sticky until read)
-    unsigned long long* h_status = nullptr;     // pinned copy of d_queue[1], written by the stream after every render launch
-    bool status_pending = false;                // a render launch whose watchdog word has not been looked at yet
+    unsigned long long* h_status = nullptr;     // pinned copies of the watchdog words, written by the stream after every Julia launch:
+                                                // [0] d_queue[1] (the context's own workspace), [1] the fixed workspace's (rt_render_device_noalloc)
+    unsigned status_pending = 0;                // bit s: a Julia launch whose watchdog word h_status[s] has not been looked at yet
     bool debug_force_abort = false;             // RT_OPT_DEBUG_FORCE_ABORT
     bool elide_unlit_shadows = true;            // RT_OPT_ELIDE_UNLIT_SHADOWS
     bool cull_photon_roots = true;              // RT_OPT_CULL_PHOTON_ROOTS
-    unsigned long long* status_flag = nullptr;  // device word the pending status was copied from (cleared once seen)
+    unsigned long long* status_flag[2] = {nullptr, nullptr};   // device words the pending statuses were copied from (each cleared once seen)
     unsigned char* noalloc_scratch = nullptr;   // address of `scratch` on this context's device (hipGetSymbolAddress)
     // persistent grid of the render kernels for the uploaded scene ([0] plain, [1] counters build): asked once per upload
     int trace_blocks_per_cu[2] = {0, 0};
@@ -369,9 +370,12 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     job.elide_unlit = (ctx->elide_unlit_shadows && !stats) ? 1u : 0u;
     if (ctx->upload_in_flight && stream != nullptr) RT_HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ev_upload, 0));   // the scene's copy ran on the default stream
     if (fixed != nullptr) {
-        // the fixed workspace is shared by every call on this GPU and keeps the last call's contents: both queue
-        // words and the counters start at zero (the frame stacks and the sample buffer are written before they are read)
-        RT_HIP_TRY(ctx, hipMemsetAsync(ws.queue, 0, kNoAllocHeaderBytes, stream));
+        // the fixed workspace is shared by every call on this GPU and keeps the last call's contents: the queue head
+        // and the counters start at zero (the frame stacks and the sample buffer are written before they are read).
+        // Word [1], the watchdog flag, is sticky here too: cleared only once a host has seen it (launch_status), so
+        // that two launches without rt_launch_status in between do not lose the first one's abandonment
+        RT_HIP_TRY(ctx, hipMemsetAsync(ws.queue, 0, sizeof(unsigned long long), stream));
+        RT_HIP_TRY(ctx, hipMemsetAsync(ws.counters, 0, C_COUNT * sizeof(unsigned long long), stream));
     } else {
         // [0] queue head: cleared per launch.  [1] watchdog flag: sticky, cleared only once the host has seen it (launch_status)
         RT_HIP_TRY(ctx, hipMemsetAsync(ws.queue, 0, sizeof(unsigned long long), stream));
@@ -396,23 +400,34 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
         hipLaunchKernelGGL(sum_samples_kernel, dim3(g), dim3(256), 0, stream, job.samples, job.out, job.n_pixels, job.samples_per_pixel, ctx->dev.inv_samples);
         RT_HIP_TRY(ctx, hipGetLastError());
     }
-    if (julia) RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ws.queue + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    if (julia) {
+        // the word stays set on the device until launch_status has seen it, so a later launch's copy still carries an
+        // earlier launch's abandonment; the two workspaces have a word (and a pinned copy) each
+        const int slot = fixed != nullptr ? 1 : 0;
+        RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status + slot, ws.queue + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        ctx->status_pending |= 1u << slot;
+        ctx->status_flag[slot] = ws.queue + 1;
+    }
     RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream));
     ctx->events_pending = true;
-    ctx->status_pending = julia;
-    ctx->status_flag = ws.queue + 1;
     return RT_OK;
 }
 
 // Waits for the last render launch and reports a launch that trace_julia_kernel's watchdog abandoned (a wave waited
 // too long on the job queues: the picture is incomplete).  The device flag stays set until it has been seen here.
 int launch_status(rt_ctx* ctx) {
-    if (!ctx->status_pending) return RT_OK;
-    RT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_end));
-    ctx->status_pending = false;
-    if (*ctx->h_status == 0) return RT_OK;
-    *ctx->h_status = 0;
-    RT_HIP_TRY(ctx, hipMemset(ctx->status_flag, 0, sizeof(unsigned long long)));
+    if (ctx->status_pending == 0u) return RT_OK;
+    RT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_end));   // the last launch's: every copy enqueued before it has landed
+    const unsigned pending = ctx->status_pending;
+    ctx->status_pending = 0u;
+    bool abandoned = false;
+    for (int slot = 0; slot < 2; slot++) {
+        if ((pending & (1u << slot)) == 0u || ctx->h_status[slot] == 0) continue;
+        abandoned = true;
+        ctx->h_status[slot] = 0;
+        RT_HIP_TRY(ctx, hipMemset(ctx->status_flag[slot], 0, sizeof(unsigned long long)));
+    }
+    if (!abandoned) return RT_OK;
     return fail(ctx, RT_ERR_HIP, "trace_julia_kernel: a wave waited too long on the job queues and the launch was abandoned");
 }
 
@@ -704,7 +719,7 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
         hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), C_COUNT * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&ctx->d_dep_words), 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->h_dep_words), 4 * sizeof(unsigned long long)) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), sizeof(unsigned long long)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), 2 * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&ctx->ev_dep) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) {
         delete ctx;
@@ -723,7 +738,7 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
     }
     (void)hipMemset(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long));
     (void)hipMemset(ctx->d_queue, 0, 256);   // [0] queue head, [1] watchdog flag of trace_julia_kernel
-    *ctx->h_status = 0;
+    ctx->h_status[0] = ctx->h_status[1] = 0;
     *out_ctx = ctx;
     return RT_OK;
 }

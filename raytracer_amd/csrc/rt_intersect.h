@@ -317,6 +317,14 @@ RT_DEV bool julia_distance_tail_fast(float m2, float d2, float& out) {
 // of its value); everything else, and every operand outside m2 in [16, 1e30), goes to that function.
 // Model and sweep against the reference's expression: tools/fast_tail_model.c (lean), tests/test_fast_tail_model.py.
 RT_DEV bool julia_distance_tail_lean(float m2, float d2, float& out) {
+    if (d2 == __builtin_inff() && m2 > 0.0f && m2 < __builtin_inff()) {
+        // interior point (the estimate ended by the overflow of d2): sqrt(m2/inf) = +0 times a finite logarithm, a zero
+        // with the logarithm's sign, as in julia_distance_tail_fast.  Decided here because one such lane in a marcher
+        // wave's step phase (2.4 % of C4's steps: six phases in ten hold one) would send the whole wave through the
+        // general form's code
+        out = m2 < 1.0f ? -0.0f : 0.0f;
+        return true;
+    }
     if (!(m2 >= 16.0f && m2 < 1e30f)) return false;
     const float q = m2 / d2;
     if (!(q >= 1e-30f && q < 1e30f)) return false;

@@ -118,6 +118,39 @@ RT_DEV void bump(Counters& n, int slot, unsigned long long by = 1) {
     if (STATS) n.v[slot] += by;
 }
 
+// Developer build (-DRT_PHASE_TIMING, tools/phase_split.py): section clocks of the Julia kernel's waves without the per-lane
+// counters of the STATS build (which double its time and so distort the shares): a few wave-uniform accumulators,
+// added to the launch's counter words when the wave ends.
+#ifdef RT_PHASE_TIMING
+constexpr bool kPhaseTiming = true;
+#else
+constexpr bool kPhaseTiming = false;
+#endif
+struct WaveClocks {
+    static constexpr int kSlots = 12;
+    unsigned long long acc[kSlots];
+    int slot_of[kSlots];
+    long long mark;
+    RT_DEV void begin(const int* slots, int n_slots) {
+        for (int i = 0; i < kSlots; i++) {
+            acc[i] = 0ull;
+            slot_of[i] = i < n_slots ? slots[i] : -1;
+        }
+        mark = static_cast<long long>(__builtin_readcyclecounter());
+    }
+    RT_DEV void charge(int i) {
+        const long long now = static_cast<long long>(__builtin_readcyclecounter());
+        acc[i] += static_cast<unsigned long long>(now - mark);
+        mark = now;
+    }
+    RT_DEV void add(int i, unsigned long long by) { acc[i] += by; }
+    RT_DEV void flush(unsigned long long* out) const {
+        if ((threadIdx.x & 63) != 0) return;
+        for (int i = 0; i < kSlots; i++)
+            if (slot_of[i] >= 0 && acc[i] != 0ull) atomicAdd(&out[slot_of[i]], acc[i]);
+    }
+};
+
 // A candidate hit of scene object `obj` reaches the per-query acceptance rule
 // (src/raytracer.cpp:128-141 for Q_TRACE, :222-226 for Q_SHADOW, src/photonmap.cpp:68-74 for Q_PHOTON).
 // Where the record of an accepted hit goes.  Kept in the lane's registers it stays live over the whole object loop;
@@ -1125,7 +1158,15 @@ static_assert((kJuliaQueueCap & (kJuliaQueueCap - 1)) == 0, "ring size");
 #ifndef RT_JULIA_SHADER_MIN_BATCH
 #define RT_JULIA_SHADER_MIN_BATCH 48       // a shader wave waits for this many ready contexts of one kind while the marchers have work
 #endif
-constexpr unsigned long long kStuckTicks = 100000000ull;   // 1 s of the 100 MHz clock without any progress in the workgroup
+// The watchdog gives a launch up on two kinds of evidence together: no progress in the workgroup for kStuckTicks of the
+// 100 MHz wall clock (1 s) AND kStuckPolls looks at the heartbeat by THIS wave in that time, none of them after a gap.
+// Wall time alone is not evidence: a workgroup that the hardware scheduler switches out (another process's grid on
+// the same GPU, a debugger, a preempted queue) sleeps with its clock running, and the first wave restored would
+// find a second gone by with the heartbeat unchanged before the working waves are back.  A poll that comes more than
+// kPollGapTicks after the previous one (0.5 ms; a poll takes a microsecond) therefore starts the wait afresh.
+constexpr unsigned long long kStuckTicks = 100000000ull;
+constexpr unsigned kStuckPolls = 20000u;
+constexpr unsigned long long kPollGapTicks = 50000ull;
 
 enum CtxWord : int {
     CW_QO = 0, CW_QMAX = 3, CW_QD = 4, CW_FLAGS = 7,
@@ -1209,9 +1250,18 @@ RT_DEV unsigned ring_entry(JuliaRing& q, unsigned i, unsigned* abort_flag) {
     const unsigned short* w = &q.slot[i & (kJuliaQueueCap - 1)];
     unsigned v = lds_load(w);
     if (!ring_word_is(v, i)) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        // (the producer reserved the slot and is about to write it: normally a few hundred cycles)
+        unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), last = t0;
+        unsigned polls = 0;
         while (!ring_word_is(v = lds_load(w), i)) {
-            if (__builtin_amdgcn_s_memrealtime() - t0 > kStuckTicks) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (now - last > kPollGapTicks) {      // this wave was away: so, probably, was the producer
+                t0 = now;
+                polls = 0;
+            }
+            last = now;
+            polls++;
+            if (now - t0 > kStuckTicks && polls > kStuckPolls) {
                 lds_store(abort_flag, 1u);
                 return 0u;
             }
@@ -1228,18 +1278,23 @@ struct IdleWatch {
     unsigned seen;
     unsigned long long since;
     bool armed;
+    unsigned long long last = 0ull;   // time of the previous poll
+    unsigned polls = 0u;              // polls since `since` that saw the same heartbeat, without a gap between them
 };
 RT_DEV void idle_wait(PoolShared& sh, IdleWatch& w) {
     __builtin_amdgcn_s_sleep(8);
     const unsigned hb = lds_load(&sh.heartbeat);
     const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-    if (!w.armed || hb != w.seen) {
+    if (!w.armed || hb != w.seen || now - w.last > kPollGapTicks) {
+        // progress, or this wave was away (then so was the workgroup: see kStuckPolls): the wait starts afresh
         w.armed = true;
         w.seen = hb;
         w.since = now;
-    } else if (now - w.since > kStuckTicks) {
+        w.polls = 0u;
+    } else if (++w.polls > kStuckPolls && now - w.since > kStuckTicks) {
         lds_store(&sh.abort, 1u);
     }
+    w.last = now;
 }
 RT_DEV void beat(PoolShared& sh) {
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&sh.heartbeat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1347,7 +1402,7 @@ RT_DEV void ctx_store_hot(float* c, const Lane& L, bool waiting) {
 
 // ---- marcher waves ------------------------------------------------------------------------------------------
 template <bool STATS>
-RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n) {
+RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n, unsigned long long* counter_words) {
     const int lane = threadIdx.x & 63;
     bool has = false, busy = false;
     unsigned owner = 0, jidx = 0, jstep = 0, it = 0, okind = 0, prev_it = 0;
@@ -1355,13 +1410,23 @@ RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n) {
     JuliaPk s = julia_pk_begin({0, 0, 0, 0});
     PkF2 cp = {0, 0}, cq = {0, 0};
     float cut = 0.0f;
-    IdleWatch watch = {0u, 0ull, false};
+    IdleWatch watch = {0u, 0ull, false, 0ull, 0u};
     long long t_mark = STATS ? clock64() : 0;
+    constexpr bool TIMED = kPhaseTiming && !STATS;
+    WaveClocks wc;
+    enum { W_MARCH, W_TAIL, W_REFILL, W_IDLE, W_NORMAL, W_PHASES, W_LANES, W_BLOCKS, W_TAIL_LANES, W_NORMAL_PHASES, W_NORMAL_LANES, W_BUSY_LANES };
+    if (TIMED) {
+        const int slots[] = {D_MARCH_CYCLES, D_M_TAIL_CYCLES, D_M_REFILL_CYCLES, D_M_IDLE_CYCLES, D_NORMAL_CYCLES, D_MARCH_PHASES, D_MARCH_LANES,
+                             D_DE_WAVE_ITERS, D_M_TAIL_LANES, D_NORMAL_PHASES, D_NORMAL_LANES, D_MARCH_HAS_SUM};
+        wc.begin(slots, 12);
+    }
     auto charge = [&](int slot) {
         if (STATS) {
             const long long now = clock64();
             if (lane == 0) n.v[slot] += static_cast<unsigned long long>(now - t_mark);
             t_mark = now;
+        } else if (TIMED) {
+            wc.charge(slot == D_MARCH_CYCLES ? W_MARCH : slot == D_M_TAIL_CYCLES ? W_TAIL : slot == D_M_REFILL_CYCLES ? W_REFILL : slot == D_M_IDLE_CYCLES ? W_IDLE : W_NORMAL);
         }
     };
     unsigned round = 0;
@@ -1412,6 +1477,10 @@ RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n) {
                 beat(sh);
                 if (STATS && lane == 0) n.v[D_NORMAL_PHASES]++;
                 if (STATS && static_cast<unsigned>(lane) < got) n.v[D_NORMAL_LANES]++;
+                if (TIMED) {
+                    wc.add(W_NORMAL_PHASES, 1);
+                    wc.add(W_NORMAL_LANES, got);
+                }
                 charge(D_NORMAL_CYCLES);
                 continue;
             }
@@ -1460,6 +1529,10 @@ RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n) {
         charge(D_M_REFILL_CYCLES);
         if (STATS && lane == 0) n.v[D_MARCH_PHASES]++;
         if (STATS && has) n.v[D_MARCH_LANES]++;
+        if (TIMED) {
+            wc.add(W_PHASES, 1);
+            wc.add(W_LANES, static_cast<unsigned>(n_has));
+        }
         // ---- estimator iterations, four at a time, until enough lanes wait for their march step
         for (;;) {
             if (has && busy) {
@@ -1477,11 +1550,16 @@ RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n) {
             }
             if (STATS && lane == 0) n.v[D_DE_WAVE_ITERS] += 256ull;
             const int n_busy = __popcll(__ballot(has && busy));
+            if (TIMED) {
+                wc.add(W_BLOCKS, 1);                                   // estimator blocks of four passes ...
+                wc.add(W_BUSY_LANES, static_cast<unsigned>(n_busy));   // ... and the lanes still busy after each
+            }
             if (n_busy == 0 || (n_has - n_busy) * 8 >= n_has * RT_JULIA_STEP_EIGHTHS) break;
         }
         charge(D_MARCH_CYCLES);
         if (STATS && lane == 0) n.v[D_M_TAIL_BLOCKS]++;
         if (STATS && has && !busy) n.v[D_M_TAIL_LANES]++;
+        if (TIMED) wc.add(W_TAIL_LANES, static_cast<unsigned>(__popcll(__ballot(has && !busy))));
         // ---- march steps of the lanes whose estimate is complete (src/objects.cpp:206-221)
         bool converged = false, miss_t = false, miss_s = false;
         if (has && !busy) {
@@ -1519,6 +1597,7 @@ RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n) {
         beat(sh);
         charge(D_M_TAIL_CYCLES);
     }
+    if (TIMED) wc.flush(counter_words);
 }
 
 #if RT_JULIA_TAIL_RING
@@ -1544,7 +1623,7 @@ RT_DEV void julia_marcher_pooled(const DevScene& sc, PoolShared& sh, Counters& n
     unsigned owner = 0, it = 0;
     JuliaPk s = julia_pk_begin({0, 0, 0, 0});
     PkF2 cp = {0, 0}, cq = {0, 0};
-    IdleWatch watch = {0u, 0ull, false};
+    IdleWatch watch = {0u, 0ull, false, 0ull, 0u};
     long long t_mark = STATS ? clock64() : 0;
     auto charge = [&](int slot) {
         if (STATS) {
@@ -1724,14 +1803,23 @@ RT_DEV void julia_marcher_pooled(const DevScene& sc, PoolShared& sh, Counters& n
 template <bool STATS>
 RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob& job, PoolShared& sh, Counters& n, WaveIds& wave_ids) {
     const int lane = threadIdx.x & 63;
-    IdleWatch watch = {0u, 0ull, false};
+    IdleWatch watch = {0u, 0ull, false, 0ull, 0u};
     unsigned patience = 0;
     long long t_mark = STATS ? clock64() : 0;
+    constexpr bool TIMED = kPhaseTiming && !STATS;
+    WaveClocks wc;
+    enum { W_RESOLVE, W_QUERY, W_WAIT, W_RPHASES, W_RLANES, W_QPHASES, W_QLANES };
+    if (TIMED) {
+        const int slots[] = {D_RESOLVE_CYCLES, D_QUERY_CYCLES, D_T_WAIT_CYCLES, D_RESOLVE_PHASES, D_RESOLVE_LANES, D_QUERY_PHASES, D_QUERY_LANES};
+        wc.begin(slots, 7);
+    }
     auto charge = [&](int slot) {
         if (STATS) {
             const long long now = clock64();
             if (lane == 0) n.v[slot] += static_cast<unsigned long long>(now - t_mark);
             t_mark = now;
+        } else if (TIMED) {
+            wc.charge(slot == D_RESOLVE_CYCLES ? W_RESOLVE : slot == D_QUERY_CYCLES ? W_QUERY : W_WAIT);
         }
     };
     float* const wg_frames = job.stack + static_cast<size_t>(blockIdx.x) * kPoolCtx * (sc.max_bounces + 1) * kFrameRecordWords;
@@ -1784,6 +1872,10 @@ RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob&
         if (STATS) {
             if (lane == 0) n.v[D_RESOLVE_PHASES]++;
             if (mine) n.v[D_RESOLVE_LANES]++;
+        }
+        if (TIMED) {
+            wc.add(W_RPHASES, 1);
+            wc.add(W_RLANES, got);
         }
         // ---- a finished Julia job: Julia::intersect's last checks and the acceptance rule; then the scene's next set
         bool push_job = false;
@@ -1839,6 +1931,10 @@ RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob&
                 if (lane == 0) n.v[D_QUERY_PHASES]++;
                 if (q) n.v[D_QUERY_LANES]++;
             }
+            if (TIMED) {
+                wc.add(W_QPHASES, 1);
+                wc.add(W_QLANES, static_cast<unsigned>(__popcll(__ballot(q))));
+            }
             const BvhStackLds no_lds_stack = {nullptr, 0u, 0u, sc.bvh_nodes};
             query_objects<STATS>(sc, L, q, no_lds_stack, n, ctx_hit_sink(my_ctx));
             if (q) {
@@ -1869,6 +1965,7 @@ RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob&
 #endif
         charge(D_QUERY_CYCLES);
     }
+    if (TIMED) wc.flush(job.counters);
 }
 
 template <bool STATS>
@@ -1904,7 +2001,7 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
 #if RT_JULIA_TAIL_RING
         julia_marcher_pooled<STATS>(sc, sh, n);
 #else
-        julia_marcher<STATS>(sc, sh, n);
+        julia_marcher<STATS>(sc, sh, n, job.counters);
 #endif
     } else {
         const unsigned shader_wave = blockIdx.x * (kJuliaWaves - kJuliaMarcherWaves) + (wave - kJuliaMarcherWaves);

@@ -83,11 +83,30 @@ class HipRenderer:
             return [(self, None)]
         n = max(2, int(os.environ.get("RT_DRIVER_LANES", "2")))
         if len(getattr(self, "_twins", [])) != n - 1:
+            self.close_twins()
             self._twins = [HipRenderer(self.device.index) for _ in range(n - 1)]
             self._streams = [torch.cuda.Stream(self.device) for _ in range(n)]
         for t in self._twins:
             t.busy_events = [] if self.busy_events is not None else None
+            # a twin renders alternate units of the same job: it must run with the options set on this renderer's context
+            # (photon order, lens seed, BVH threshold, shadow elision ...), whenever they were set
+            if t.ctx.options != self.ctx.options:
+                for option in set(t.ctx.options) - set(self.ctx.options):
+                    raise RuntimeError("option %d was set on a twin context only" % option)
+                for option, value in self.ctx.options.items():
+                    if t.ctx.options.get(option) != value:
+                        t.ctx.set_option(option, value)
         return [(self, self._streams[0])] + [(t, self._streams[k + 1]) for k, t in enumerate(self._twins)]
+
+    def close_twins(self):
+        for t in getattr(self, "_twins", []):
+            t.close()
+        self._twins = []
+
+    def close(self):
+        """Destroys the context (and those of the twins lanes() made)."""
+        self.close_twins()
+        self.ctx.close()
 
     def _photon_pass(self, enqueue, defer_check=False):
         """Enqueues a photon pass; if it outgrew the record buffer of the ordered sum (the library has resized it

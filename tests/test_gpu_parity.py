@@ -372,6 +372,13 @@ def test_units_alternating_over_two_contexts_give_the_same_frames(monkeypatch):
     assert reruns.count(False) >= 2
     for a, b in zip(got, want[0]):
         assert np.array_equal(a, b)
+    # options set on the renderer's context reach the twin that renders the alternate units, whenever they were set
+    r.ctx.set_option(capi.RT_OPT_DOF_SEED, 7)
+    r.ctx.set_option(capi.RT_OPT_PHOTON_ORDER, 0)
+    twin = r.lanes()[1][0]
+    assert twin.ctx.options == r.ctx.options and twin.ctx.ordered_photons is False
+    r.close()
+    assert not twin.ctx._ctx
 
 
 # The reference built with its OWN Makefile flags (-Ofast -flto -march=native) is the secondary parity

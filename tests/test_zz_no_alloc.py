@@ -93,3 +93,29 @@ def test_noalloc_rejects_what_does_not_fit():
         assert float(out.max()) > 0
     finally:
         ctx.close()
+
+
+def test_an_abandoned_launch_is_not_lost_under_later_launches():
+    """The watchdog word is sticky in both workspaces until rt_launch_status has seen it: an abandoned Julia launch
+    (RT_OPT_DEBUG_FORCE_ABORT) followed, unchecked, by further launches of either entry point is still reported."""
+    ctx = capi.Context(0)
+    try:
+        sc = capi.Scene(scene_path("examples2/4_julia.xml"), 0.0)
+        sc.set_camera(64, 48, 1)
+        ctx.upload(sc)
+        out = torch.zeros((64 * 48, 4), dtype=torch.float32, device="cuda:0")
+        for first, second in (("noalloc", "noalloc"), ("device", "noalloc"), ("noalloc", "device")):
+            launch = {"noalloc": ctx.render_device_noalloc, "device": ctx.render_device}
+            ctx.set_option(capi.RT_OPT_DEBUG_FORCE_ABORT, 1)
+            launch[first](out.data_ptr(), None)
+            ctx.set_option(capi.RT_OPT_DEBUG_FORCE_ABORT, 0)
+            launch[second](out.data_ptr(), None)          # a healthy launch on top, its status unchecked so far
+            with pytest.raises(capi.RtError, match="abandoned"):
+                ctx.launch_status()
+            ctx.launch_status()                             # seen once: cleared
+            launch[second](out.data_ptr(), None)
+            ctx.launch_status()
+            torch.cuda.synchronize()
+            assert float(out.max()) > 0
+    finally:
+        ctx.close()

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--ss", type=int, default=0)
     ap.add_argument("--no-oracle", action="store_true")
     ap.add_argument("--stats", action="store_true")
+    ap.add_argument("--timing", action="store_true", help="library built with -DRT_PHASE_TIMING: print its section clocks")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--save", default="")
@@ -45,8 +46,9 @@ def main():
             times.append(s2.kernel_ms)
         print("%s %dx%d ss%d: photon %.3f ms, render kernel ms %s" % (os.path.basename(path), sc.width, sc.height,
               sc.desc.camera.supersampling, pst.kernel_ms, ["%.3f" % t for t in times]), flush=True)
-        if args.stats:
-            print("  hip stats", {k: v for k, v in st.as_dict().items() if v}, flush=True)
+        if args.stats or args.timing:
+            if args.stats:
+                print("  hip stats", {k: v for k, v in st.as_dict().items() if v}, flush=True)
             import ctypes as C
             words = (C.c_uint64 * 96)()
             nw = capi.hip_lib().rt_debug_counters(ctx._ctx, words, 96)
@@ -60,7 +62,19 @@ def main():
                      "march_has_sum", "march_polls", "chunk_tests", "chunk_passed", "chunk_lanes", "sphere_culls", "sphere_passed",
                      "resolve_mixed", "resolve_minority_lanes", "photon_cull_violations"]
             dbg = dict(zip(names, list(words)[18:nw]))
-            print("  scheduler", dbg, flush=True)
+            print("  scheduler", {k: v for k, v in dbg.items() if v}, flush=True)
+            if dbg["march_cycles"]:
+                mt = sum(dbg[k] for k in ("march_cycles", "m_tail_cycles", "m_refill_cycles", "m_idle_cycles", "normal_cycles"))
+                print("   marcher waves: " + ", ".join("%s %.1f%%" % (k, 100.0 * dbg[k] / mt) for k in
+                      ("march_cycles", "m_tail_cycles", "m_refill_cycles", "m_idle_cycles", "normal_cycles")), flush=True)
+                blocks = dbg["de_wave_iter_slots"] if args.timing else dbg["de_wave_iter_slots"] // 256
+                print("   estimator blocks %d (%.0f clk each), blocks per march phase %.2f, tail phases %d (%.0f clk each, %.1f lanes), lanes holding a job %.1f" % (
+                    blocks, dbg["march_cycles"] / max(1, blocks), blocks / max(1, dbg["march_phases"]), dbg["march_phases"],
+                    dbg["m_tail_cycles"] / max(1, dbg["march_phases"]), dbg["m_tail_lanes"] / max(1, dbg["march_phases"]), dbg["march_lanes"] / max(1, dbg["march_phases"])), flush=True)
+                if args.timing:
+                    print("   busy lanes per estimator block %.1f" % (dbg["march_has_sum"] / max(1, blocks)), flush=True)
+                st_ = sum(dbg[k] for k in ("resolve_cycles", "query_cycles", "t_wait_cycles"))
+                print("   shader waves: " + ", ".join("%s %.1f%%" % (k, 100.0 * dbg[k] / max(1, st_)) for k in ("resolve_cycles", "query_cycles", "t_wait_cycles")), flush=True)
             for ph in ("query", "march", "normal", "resolve"):
                 if dbg[ph + "_phases"]:
                     print("   %s: lanes/phase %.1f, cycles/phase %.0f, share of cycles %.1f%%" % (
@@ -71,7 +85,7 @@ def main():
             rc = max(1, dbg["resolve_cycles"])
             print("   inside resolve: " + ", ".join("%s %.1f%%" % (k[2:], 100.0 * dbg[k] / rc) for k in
                   ("r_node", "r_light", "r_shadowsetup", "r_fresnel", "r_return", "r_fetch")), flush=True)
-            if dbg["de_wave_iter_slots"]:
+            if dbg["de_wave_iter_slots"] and args.stats:
                 print("   DE lane-iterations / wave slots = %.3f" % (st.julia_de_iterations / dbg["de_wave_iter_slots"]), flush=True)
         if args.save:
             capi.png_write(args.save, capi.quantize(img))
