@@ -38,8 +38,31 @@ raytracer_amd/rt_amd: $(wildcard raytracer_amd/host/*.cpp) $(HOST_HDRS) raytrace
 oracle:
 	$(MAKE) -C oracle
 
+# ---- sanitizer builds of the host code (reference Makefile:10-11 has the flags commented out) ------------
+#   make asan      host loader + PNG/APNG + oracle under AddressSanitizer + UBSan: tools/sanitize_host (also run by
+#                  tests/test_sanitizers.py), then librt_hip's host code (BVH builder) the same way: tools/sanitize_bvh
+#   make tsan      the same host program under ThreadSanitizer (four loader threads sharing the asset cache)
+SAN_SRCS = tools/sanitize_host.cpp $(HOST_SRCS) oracle/rt_oracle.cpp
+build/asan/sanitize_host: $(SAN_SRCS) $(HOST_HDRS)
+	@mkdir -p build/asan
+	$(CXX) -O1 -g -std=c++17 -pthread -ffp-contract=off -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -o $@ $(SAN_SRCS) -lz
+build/tsan/sanitize_host: $(SAN_SRCS) $(HOST_HDRS)
+	@mkdir -p build/tsan
+	$(CXX) -O1 -g -std=c++17 -pthread -ffp-contract=off -fsanitize=thread -o $@ $(SAN_SRCS) -lz
+build/asan/sanitize_bvh: tools/sanitize_bvh.cpp $(HIP_SRCS) $(wildcard raytracer_amd/csrc/*.h) include/rt_hip.h
+	@mkdir -p build/asan
+	$(HIPCC) $(HIPFLAGS) -g -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-omit-frame-pointer -o $@ tools/sanitize_bvh.cpp $(HIP_SRCS)
+SCENE_DIRS = scenes/examples scenes/examples2 scenes/examples3
+asan-host: build/asan/sanitize_host
+	ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=print_stacktrace=1 build/asan/sanitize_host $(SCENE_DIRS)
+asan-bvh: build/asan/sanitize_bvh
+	ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 build/asan/sanitize_bvh
+asan: asan-host asan-bvh
+tsan: build/tsan/sanitize_host
+	build/tsan/sanitize_host $(SCENE_DIRS)
+
 clean:
 	rm -f raytracer_amd/*.so raytracer_amd/rt_amd
 	rm -rf build
 	$(MAKE) -C oracle clean
-.PHONY: all host hip cli oracle clean
+.PHONY: all host hip cli oracle clean asan asan-host asan-bvh tsan

@@ -14,7 +14,8 @@
  * caught once in main (reference src/main.cpp:202-205).
  *
  * Threading: calls on one rt_ctx are serialised by the caller.  Different contexts (one per GPU)
- * may be driven from different host threads or processes.
+ * may be driven from different host threads or processes; see rt_create for the one constraint on
+ * the process's FIRST call.
  */
 #ifndef RT_HIP_H
 #define RT_HIP_H
@@ -182,6 +183,14 @@ typedef struct rt_stats {
 
 typedef struct rt_ctx rt_ctx;
 
+/* rt_create makes the process's first HIP calls when nothing else has.  CONSTRAINT (of the HIP runtime, not of this
+ * library; found with tools/hip_init_race.cpp, a host-only program with none of this library's code in it): while the
+ * runtime starts up it unmaps a page it no longer owns, so a thread that maps memory at that moment — malloc of a
+ * large buffer, a new thread's stack, a file mapping — can find a one-page hole in what it was just given (SIGSEGV on
+ * first touch; 2 in 200 runs).  Make the first rt_create (or any other first HIP call) while the process's other
+ * threads are not allocating, ideally before they exist; afterwards contexts may be created, used and destroyed from
+ * any thread (calls made with the runtime up were never seen to disturb another thread's mappings: 300 runs).
+ * rt_create calls are serialised among themselves. */
 int  rt_create(rt_ctx** out_ctx, int device_id);
 void rt_destroy(rt_ctx* ctx);
 const char* rt_last_error(const rt_ctx* ctx_or_null);

@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -704,6 +705,10 @@ const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->error.c_str() :
 int rt_create(rt_ctx** out_ctx, int device_id) {
     if (out_ctx == nullptr) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "rt_create: out_ctx is NULL");
     *out_ctx = nullptr;
+    // One rt_create at a time: the first one makes the process's first HIP calls, and the runtime's start-up is not safe
+    // beside threads that map or unmap memory (include/rt_hip.h) — at least this library's own threads stay out of it.
+    static std::mutex create_mutex;
+    const std::lock_guard<std::mutex> one_at_a_time(create_mutex);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device is visible (this library has no CPU fallback)");
     if (device_id < 0 || device_id >= count) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "device %d out of range (0..%d)", device_id, count - 1);

@@ -223,13 +223,13 @@ void render_video_motion_blur(const SceneModel& orig) {
 
 // ---- several GPUs from one process ----------------------------------------------------------------------------------
 
-// One session (rt_ctx) per device, created concurrently.
+// One session (rt_ctx) per device, created one after the other on the calling thread, before this process has any
+// other thread: the HIP runtime's start-up must not run beside threads that map or unmap memory (include/rt_hip.h,
+// rt_create; tools/hip_init_race.cpp) — and starting a thread maps its stack.
 class DevicePool {
 public:
     explicit DevicePool(const std::vector<int>& devices) {
-        std::vector<std::future<std::unique_ptr<GpuSession>>> made;
-        for (int d : devices) made.push_back(std::async(std::launch::async, [d]() { return std::make_unique<GpuSession>(d); }));
-        for (auto& m : made) sessions_.push_back(m.get());
+        for (int d : devices) sessions_.push_back(std::make_unique<GpuSession>(d));
     }
     size_t size() const { return sessions_.size(); }
     GpuSession& operator[](size_t i) { return *sessions_[i]; }
@@ -415,8 +415,11 @@ std::vector<int> device_list(int n) {
 
 }  // namespace
 
-// RT_AMD_BACKTRACE=1: print the stack of a crashing thread (developer aid)
-extern "C" void crash_backtrace(int sig) {
+// RT_AMD_BACKTRACE=1: print the faulting address and the stack of a crashing thread (developer aid)
+extern "C" void crash_backtrace(int sig, siginfo_t* info, void*) {
+    char line[96];
+    const int len = snprintf(line, sizeof line, "signal %d at address %p, si_code %d\n", sig, info ? info->si_addr : nullptr, info ? info->si_code : 0);
+    if (len > 0) (void)!write(STDERR_FILENO, line, static_cast<size_t>(len));
     void* frames[64];
     const int n = backtrace(frames, 64);
     backtrace_symbols_fd(frames, n, STDERR_FILENO);
@@ -426,8 +429,12 @@ extern "C" void crash_backtrace(int sig) {
 
 int main(int argc, char* argv[]) {
     if (std::getenv("RT_AMD_BACKTRACE")) {
-        signal(SIGSEGV, crash_backtrace);
-        signal(SIGABRT, crash_backtrace);
+        struct sigaction sa;
+        std::memset(&sa, 0, sizeof sa);
+        sa.sa_sigaction = crash_backtrace;
+        sa.sa_flags = SA_SIGINFO;
+        sigaction(SIGSEGV, &sa, nullptr);
+        sigaction(SIGABRT, &sa, nullptr);
     }
     int n_devices = 1;
     if (const char* env = std::getenv("RT_AMD_DEVICES")) n_devices = std::atoi(env);
@@ -464,8 +471,13 @@ int main(int argc, char* argv[]) {
         // The GPU runtime starts up first (some 35 ms warm: device context, code object); like the reference's process
         // start-up it lies before every timer.  It is NOT overlapped with the scene parse: with the parse running on
         // this thread while another one sat in the runtime's initialisation, 2 of ~300 runs died with SIGSEGV in a
-        // memcpy of a freshly allocated texture buffer (tools/cli_stress.sh, RT_AMD_BACKTRACE=1); the loader is clean
-        // under ASan/UBSan with a noisy allocator thread beside it, and none of 200 sequential runs failed.
+        // memcpy into a freshly allocated texture buffer (tools/cli_stress.sh, RT_AMD_BACKTRACE=1).  Cause, found with
+        // a host-only program that has none of this repository's code in it (tools/hip_init_race.cpp, 2 crashes in 200
+        // runs; /proc/self/maps at the fault): during the process's FIRST HIP calls the runtime unmaps a single page
+        // that it no longer owns — the fault address is the start of a one-page hole inside the anonymous mapping
+        // that malloc had just obtained for the other thread's multi-megabyte buffer.  HIP calls made once the runtime
+        // is up (allocations, pinned memory, copies, streams, events: 300 runs) leave other threads' mappings alone.
+        // Hence the rule of include/rt_hip.h: the first rt_create runs while no other thread maps or unmaps memory.
         (void)GpuSession::process_default();
         SceneModel scene = load_scene(argv[1]);
         if (argc >= 3) scene.output_file = argv[2];
