@@ -26,6 +26,7 @@
 // (src/raytracer.cpp:126-161); shading has no side effects, so the returned value is identical.
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <cmath>
 #include <complex>
 #include <cstdint>
@@ -240,6 +241,8 @@ V3 julia_normal(const rt_julia& j, Quat pos, float diff, Counters& n) {
 
 // Diagnostic only (oracle_march_histogram): marches by length.  A march is a chain of dependent steps, so the longest
 // ones bound the latency of a frame whatever the machine's throughput.
+thread_local uint64_t t_sample_longest_march = 0;      // longest single march of the sample being rendered
+thread_local std::vector<uint32_t>* t_march_log = nullptr;   // oracle_pixel_marches: steps of every march, bit 31 = shadow ray
 std::atomic<uint64_t> g_march_hist[16];        // marches of 2^(k-1) < steps <= 2^k
 std::atomic<uint64_t> g_march_hist_steps[16];  // ... their steps
 std::atomic<uint64_t> g_march_longest_iterations{0};   // estimator iterations of the march with the most of them
@@ -282,6 +285,8 @@ bool julia_intersect(const rt_julia& j, const Ray& ray, float max_distance, Hit*
         p = add(p, mul(d, distance));
     }
     note_march(steps, n.julia_de_iterations - iterations_before);
+    if (t_march_log != nullptr) t_march_log->push_back(steps | (max_distance != INFINITE_F ? 0x80000000u : 0u));
+    if (steps > t_sample_longest_march) t_sample_longest_march = steps;
     if (distance >= JULIA_CONVERGENCE_LIMIT) return false;
     V3 normal = julia_normal(j, {p.x, p.y, p.z, j.cut_plane}, JULIA_GRADIENT_DIFF, n);
     if (dot(normal, d) > 0.0f) normal = mul(normal, -1.0f);
@@ -517,6 +522,36 @@ V2 lens_draws(const rt_camera& cam, uint32_t x, uint32_t y, uint32_t sub) {
     return {static_cast<float>(h1 >> 8) * (2.0f / 16777216.0f) - 1.0f, static_cast<float>(h2 >> 8) * (2.0f / 16777216.0f) - 1.0f};
 }
 
+// Diagnostic only (oracle_sample_extremes): the sample (one cast_ray from the camera: a chain of dependent queries) with the
+// most Julia march steps, and the one with the most estimator iterations: {steps, iterations, queries} of each.
+std::atomic<uint64_t> g_sample_most_steps[3], g_sample_most_iterations[3];
+std::mutex g_sample_lock;
+void note_sample(uint64_t steps, uint64_t iterations, uint64_t queries) {
+    if (steps <= g_sample_most_steps[0].load(std::memory_order_relaxed) && iterations <= g_sample_most_iterations[1].load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> hold(g_sample_lock);
+    if (steps > g_sample_most_steps[0]) {
+        g_sample_most_steps[0] = steps; g_sample_most_steps[1] = iterations; g_sample_most_steps[2] = queries;
+    }
+    if (iterations > g_sample_most_iterations[1]) {
+        g_sample_most_iterations[0] = steps; g_sample_most_iterations[1] = iterations; g_sample_most_iterations[2] = queries;
+    }
+}
+thread_local uint64_t t_pixel_longest_sample = 0;
+thread_local float t_pixel_sample0[2] = {0, 0};        // of the pixel's first sample: its steps, its longest march   // steps of the longest sample of the pixel being rendered
+struct SampleNote {
+    Tracer& tr;
+    uint64_t s0, i0, q0;
+    explicit SampleNote(Tracer& t) : tr(t), s0(t.n.julia_steps), i0(t.n.julia_de_iterations), q0(t.n.julia_queries) { t_sample_longest_march = 0; }
+    ~SampleNote() {
+        note_sample(tr.n.julia_steps - s0, tr.n.julia_de_iterations - i0, tr.n.julia_queries - q0);
+        if (tr.n.julia_steps - s0 > t_pixel_longest_sample) t_pixel_longest_sample = tr.n.julia_steps - s0;
+        if (t_pixel_sample0[0] < 0.0f) {
+            t_pixel_sample0[0] = static_cast<float>(tr.n.julia_steps - s0);
+            t_pixel_sample0[1] = static_cast<float>(t_sample_longest_march);
+        }
+    }
+};
+
 // One pixel: src/raytracer.cpp:55-112.
 Col render_pixel(Tracer& tr, const CameraFrame& f, uint32_t x, uint32_t y) {
     const rt_scene_desc& sc = tr.sc;
@@ -540,9 +575,11 @@ Col render_pixel(Tracer& tr, const CameraFrame& f, uint32_t x, uint32_t y) {
                 int hue_index = 0;
                 for (float hue = 0.0f; hue < 360.0f; hue += 45.0f, hue_index++) {
                     const Col hue_color = {sc.hue_rgb[hue_index][0], sc.hue_rgb[hue_index][1], sc.hue_rgb[hue_index][2], 1.0f};
+                    SampleNote note(tr);
                     radiance = cadd(radiance, cdiv(cmulc(tr.cast_ray(ray, 0, hue / 180.0f - 1.0f), hue_color), 4.0f));
                 }
             } else {
+                SampleNote note(tr);
                 radiance = cadd(radiance, tr.cast_ray(ray, 0, 0));
             }
         }
@@ -735,6 +772,10 @@ void oracle_camera_ray(const rt_scene_desc* sc, uint32_t x, uint32_t y, uint32_t
 // Diagnostic: when set, oracle_render_rows writes every pixel's Julia march steps (all of its samples' rays) there.
 static float* g_cost_map = nullptr;
 void oracle_set_cost_map(float* per_pixel) { g_cost_map = per_pixel; }
+static float* g_longest_map = nullptr;   // ... and the steps of its longest sample (a chain of dependent queries)
+void oracle_set_longest_map(float* per_pixel) { g_longest_map = per_pixel; }
+static float* g_sample0_map = nullptr;   // ... and of its first sample: {steps, longest single march}
+void oracle_set_sample0_map(float* per_pixel_pairs) { g_sample0_map = per_pixel_pairs; }
 // Diagnostic: Julia march steps of the primary ray through the centre of pixel (x, y) alone (nearest-hit query only).
 uint64_t oracle_probe_steps(const rt_scene_desc* sc, uint32_t x, uint32_t y) {
     float r[6];
@@ -765,8 +806,15 @@ void oracle_render_rows(const rt_scene_desc* sc, const oracle_photons* photons, 
             const uint32_t y = row_begin + i * row_step;
             for (uint32_t x = 0; x < sc->camera.width; x++) {
                 const uint64_t steps_before = tr.n.julia_steps;
+                t_pixel_longest_sample = 0;
+                t_pixel_sample0[0] = -1.0f;
                 const Col c = render_pixel(tr, frame, x, y);
+                if (g_sample0_map != nullptr) {
+                    g_sample0_map[(size_t(y) * sc->camera.width + x) * 2] = t_pixel_sample0[0];
+                    g_sample0_map[(size_t(y) * sc->camera.width + x) * 2 + 1] = t_pixel_sample0[1];
+                }
                 if (g_cost_map != nullptr) g_cost_map[size_t(y) * sc->camera.width + x] = static_cast<float>(tr.n.julia_steps - steps_before);
+                if (g_longest_map != nullptr) g_longest_map[size_t(y) * sc->camera.width + x] = static_cast<float>(t_pixel_longest_sample);
                 float* px = rgba_out + (size_t(y) * sc->camera.width + x) * 4;
                 px[0] = c.r;
                 px[1] = c.g;
@@ -865,6 +913,28 @@ void oracle_march_histogram(uint64_t* counts, uint64_t* steps, uint64_t* longest
         steps[k] = g_march_hist_steps[k].exchange(0);
     }
     *longest_iterations = g_march_longest_iterations.exchange(0);
+}
+
+// Diagnostic: the Julia marches of pixel (x, y), all of its samples in order: steps, bit 31 set for shadow rays.  Returns
+// how many there were (at most `cap` are written).
+uint32_t oracle_pixel_marches(const rt_scene_desc* sc, uint32_t x, uint32_t y, uint32_t* out, uint32_t cap) {
+    std::vector<uint32_t> log;
+    t_march_log = &log;
+    Tracer tr{*sc, nullptr, {}};
+    const CameraFrame frame = camera_frame(sc->camera);
+    (void)render_pixel(tr, frame, x, y);
+    t_march_log = nullptr;
+    for (uint32_t i = 0; i < log.size() && i < cap; i++) out[i] = log[i];
+    return static_cast<uint32_t>(log.size());
+}
+
+// Diagnostic: {steps, iterations, Julia queries} of the sample with the most march steps and of the one with the most
+// estimator iterations since the last call.  Not part of any parity check.
+void oracle_sample_extremes(uint64_t* out6) {
+    for (int k = 0; k < 3; k++) {
+        out6[k] = g_sample_most_steps[k].exchange(0);
+        out6[3 + k] = g_sample_most_iterations[k].exchange(0);
+    }
 }
 
 }  // extern "C"

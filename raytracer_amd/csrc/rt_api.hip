@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -78,12 +79,19 @@ struct Workspace {
     size_t stack_bytes = 0;                   // capacity
     float4* samples = nullptr;                // [samples_per_pixel][pixels] when samples_per_pixel > 1
     size_t samples_bytes = 0;                 // capacity
+    uint32_t* sched = nullptr;                // DevJob::sched (Julia scenes with several samples per pixel), or NULL
 };
 
 // ---- rt_render_device_noalloc: the workspace of the entry point that allocates nothing --------------------------
 // One array per GPU that loads this library, held until the process ends.  Host code never passes `scratch` itself
 // to a kernel or a memset (its name is a host-side stand-in, not a device address): rt_create asks the runtime for
 // the array's address on ITS device (hipGetSymbolAddress) and every use goes through that pointer.
+#ifndef RT_JULIA_HOT_STEPS
+#define RT_JULIA_HOT_STEPS 192         // DevJob::hot_steps: measured on C4; 0 = plain order
+#endif
+#ifndef RT_JULIA_GROUP_TILES
+#define RT_JULIA_GROUP_TILES 2
+#endif
 constexpr size_t kNoAllocScratchBytes = size_t(RT_NOALLOC_SCRATCH_BYTES);
 constexpr size_t kNoAllocHeaderBytes = 4096;   // queue words at 0, counters at 256
 static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
@@ -138,7 +146,9 @@ struct rt_ctx {
     bool dep_last_pass_overflowed = false;   // sticky until the next pass is enqueued
     bool dep_key_too_narrow = false;         // a root made more deposits than the order key has bits for
     // per-call scratch, grown on demand and kept
-    Buffer samples, stack, out_staging, out8, acc, kat_a, kat_b, kat_c, kat_d;
+    Buffer samples, stack, out_staging, out8, acc, kat_a, kat_b, kat_c, kat_d, sched;
+    uint32_t julia_group_tiles = RT_JULIA_GROUP_TILES;   // DevJob::group_tiles; RT_JULIA_GROUP_TILES in the environment overrides it (developer sweeps)
+    uint32_t julia_hot_steps = RT_JULIA_HOT_STEPS;   // DevJob::hot_steps (0: plain order); RT_JULIA_HOT_STEPS in the environment overrides it (developer sweeps)
     unsigned char* h_out = nullptr;        // pinned block the synchronous entry points copy their pictures through
     size_t h_out_bytes = 0;
     unsigned long long* d_queue = nullptr;      // [0] = queue head, [1] = watchdog flag of trace_julia_kernel (sticky until read)
@@ -352,6 +362,24 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
         }
     }
     if (job.samples_per_pixel > 1) job.samples = ws.samples;
+    // Julia scenes with several samples per pixel: sample-major blocks and the hot list (DevJob::sched).  The fixed
+    // workspace of rt_render_device_noalloc has no room set aside for it and keeps the plain order: same picture.
+    job.n_tiles = job.tiles_x * job.tiles_y;
+    size_t sched_zero_words = 0, sched_list_words = 0;
+    job.group_tiles = std::max<uint32_t>(1u, ctx->julia_group_tiles);
+    job.n_groups = (job.n_tiles + job.group_tiles - 1) / job.group_tiles;
+    if (julia && fixed == nullptr && job.samples_per_pixel > 1 && ctx->julia_hot_steps != 0u) {
+        const uint64_t n_blocks = static_cast<uint64_t>(job.n_groups) * job.samples_per_pixel;
+        if (n_blocks < 0x7fffffffull) {
+            sched_zero_words = kSchedHeaderWords + job.n_groups + static_cast<size_t>((n_blocks + 31) / 32);
+            sched_list_words = static_cast<size_t>(kSchedLevels) * job.n_groups * (job.samples_per_pixel - 1);
+            rc = grow(ctx, ctx->sched, (sched_zero_words + sched_list_words) * sizeof(uint32_t));
+            if (rc != RT_OK) return rc;
+            ws.sched = static_cast<uint32_t*>(ctx->sched.ptr);
+        }
+    }
+    job.sched = ws.sched;
+    job.hot_steps = ctx->julia_hot_steps;
     job.out = d_out;
     job.id_chunk = 1;   // see fetch_ids
     // waves that draw sample ids: every wave of trace_kernel, the shader waves of trace_julia_kernel
@@ -363,6 +391,7 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     const bool tiny = job.n_samples / 64 <= 2 * (id_lanes / 64);
     job.static_blocks = tiny ? static_cast<uint32_t>((job.n_samples / 64 + id_lanes / 64 - 1) / (id_lanes / 64))
                              : static_blocks_per_wave(job.n_samples, id_lanes, julia ? RT_STATIC_SHARE_JULIA : job.samples_per_pixel > 1 ? RT_STATIC_SHARE_TRACE_SUPERSAMPLED : RT_STATIC_SHARE_TRACE);
+    if (job.sched != nullptr) job.static_blocks = 0;   // every block goes through the counter (and the claim bits)
     job.dyn_base = static_cast<uint64_t>(job.n_waves) * job.static_blocks * 64ull;
     job.stack = ws.stack;
     job.queue_head = ws.queue;
@@ -381,6 +410,10 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
         // [0] queue head: cleared per launch.  [1] watchdog flag: sticky, cleared only once the host has seen it (launch_status)
         RT_HIP_TRY(ctx, hipMemsetAsync(ws.queue, 0, sizeof(unsigned long long), stream));
         RT_HIP_TRY(ctx, hipMemsetAsync(ws.counters, 0, C_COUNT * sizeof(unsigned long long), stream));
+    }
+    if (job.sched != nullptr) {
+        RT_HIP_TRY(ctx, hipMemsetAsync(job.sched, 0, sched_zero_words * sizeof(uint32_t), stream));
+        RT_HIP_TRY(ctx, hipMemsetAsync(job.sched + sched_zero_words, 0xff, sched_list_words * sizeof(uint32_t), stream));
     }
     RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
     if (julia) {
@@ -740,6 +773,8 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
             return rc;
         }
         ctx->noalloc_scratch = static_cast<unsigned char*>(p);
+        if (const char* e = std::getenv("RT_JULIA_HOT_STEPS")) ctx->julia_hot_steps = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+        if (const char* e = std::getenv("RT_JULIA_GROUP_TILES")) ctx->julia_group_tiles = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
     }
     (void)hipMemset(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long));
     (void)hipMemset(ctx->d_queue, 0, 256);   // [0] queue head, [1] watchdog flag of trace_julia_kernel
@@ -756,7 +791,7 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->h_arena) (void)hipHostFree(ctx->h_arena);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
-    for (Buffer* b : {&ctx->scene_arena, &ctx->bvh_nodes, &ctx->atlas, &ctx->out8, &ctx->acc, &ctx->samples, &ctx->stack, &ctx->out_staging, &ctx->kat_a, &ctx->kat_b, &ctx->kat_c, &ctx->kat_d,
+    for (Buffer* b : {&ctx->scene_arena, &ctx->bvh_nodes, &ctx->atlas, &ctx->out8, &ctx->acc, &ctx->samples, &ctx->stack, &ctx->out_staging, &ctx->kat_a, &ctx->kat_b, &ctx->kat_c, &ctx->kat_d, &ctx->sched,
                       &ctx->dep_keys, &ctx->dep_vals, &ctx->dep_sorted_keys, &ctx->dep_sorted_index, &ctx->dep_long_runs, &ctx->dep_temp, &ctx->live_dirs}) {
         if (b->ptr) (void)hipFree(b->ptr);
     }

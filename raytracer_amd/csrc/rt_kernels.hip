@@ -44,7 +44,8 @@ namespace rtd {
 static_assert(RT_TRI_GROUP == kTriChunk, "the triangle loop steps by one chunk of tri_chunks");
 
 enum QueryKind : int { Q_TRACE = 0, Q_SHADOW = 1, Q_PHOTON = 2 };
-enum LaneState : int { S_IDLE = 0, S_QUERY = 1, S_WAIT = 2 /* a Julia job of this lane is with the marchers */, S_RESOLVE = 4 };
+enum LaneState : int { S_IDLE = 0, S_QUERY = 1, S_WAIT = 2 /* a Julia job of this lane is with the marchers */, S_RESOLVE = 4,
+                       S_PARK = 8 /* trace_julia_kernel: the answer to this shadow query comes from a helper context */ };
 
 constexpr int kFrameFields = 11;
 constexpr unsigned kNoTriangle = 0xffffffffu;
@@ -111,6 +112,7 @@ struct Lane {
     float wavelength;
     int hue;                 // -1 without dispersion
     unsigned long long out_slot;
+    unsigned hot;            // trace_julia_kernel: a march of this sample has been long (DevJob::hot_steps)
 };
 
 template <bool STATS>
@@ -587,6 +589,149 @@ RT_DEV bool fetch_ids(unsigned long long* head, unsigned long long dyn_base, uns
     return got;
 }
 
+// ---- long chains first (trace_julia_kernel, DevJob::sched) ------------------------------------------------------------
+// A sample is a chain of dependent queries, and a Julia march a chain of dependent steps of ~4 us each: on C4 the
+// longest sample makes 5 100 steps in 24 marches, 21 ms of latency whatever the machine's throughput, and 450 of the
+// frame's 9 000 tiles hold a sample of more than 2 000 steps.  Handed out in image order, the last of them start when
+// the frame is nearly done, and the frame ends a chain's length later (measured: 30.5 ms at 960 x 600, of which 18.5 ms
+// is throughput; a frame of a sixty-fourth of the size takes 13.2 ms).  So, where a pixel has several samples:
+//   * ids are handed out in blocks of DevJob::group_tiles tiles' worth of one sample, numbered sample-major — the first
+//     sample of every group of tiles, then the second ... — one at a time through the launch's counter;
+//   * a marcher wave that takes step number DevJob::hot_steps of a march of a FIRST sample declares the sample's tile
+//     hot: the tile's other blocks go on the hot list, and a wave that needs a block looks there first.  Cheap tiles
+//     (background, the plane) thus queue behind the tiles whose samples are long, which start within a millisecond or
+//     two of the first sample that gave them away.
+// A block with sample number >= 1 is served by whoever sets its claim bit first, through either way; results do not
+// depend on the order (every sample has its own slot in the sample buffer).
+RT_DEV unsigned sched_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RT_DEV bool sched_claim(const DevJob& job, unsigned block) {
+    uint32_t* const bits = job.sched + kSchedHeaderWords + job.n_groups;
+    const unsigned bit = 1u << (block & 31u);
+    return (atomicOr(bits + (block >> 5), bit) & bit) == 0u;
+}
+// Hot list of level k (a march reached hot_steps << k steps): the longer the march, the longer (as a rule) the sample,
+// and the sooner the tile's other samples should start; a wave looks at the highest level first.
+RT_DEV uint32_t* sched_list(const DevJob& job, unsigned level) {
+    const unsigned n_blocks = job.n_groups * job.samples_per_pixel;
+    return job.sched + kSchedHeaderWords + job.n_groups + (n_blocks + 31u) / 32u + level * job.n_groups * (job.samples_per_pixel - 1u);
+}
+// One lane: the next block for its wave, or ~0 when every block has been handed out.
+RT_DEV unsigned sched_next_block(const DevJob& job) {
+    const unsigned n_blocks = job.n_groups * job.samples_per_pixel;
+    for (;;) {
+        // first samples before everything else: they are what finds the long chains (and they hold some themselves)
+        if (__hip_atomic_load(job.queue_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < job.n_groups) {
+            const unsigned long long q = atomicAdd(job.queue_head, 1ull);
+            if (q >= n_blocks) return ~0u;
+            const unsigned b = static_cast<unsigned>(q);
+            if (b < job.n_groups || sched_claim(job, b)) return b;
+        }
+        for (int level = static_cast<int>(kSchedLevels) - 1; level >= 0; level--) {
+            uint32_t* const ctl = job.sched + 2 * level;          // [0] entries pushed, [1] entries claimed
+            const uint32_t* const list = sched_list(job, static_cast<unsigned>(level));
+            unsigned head = sched_load(ctl + 1);
+            const unsigned tail = sched_load(ctl + 0);
+            while (head < tail) {
+                const unsigned seen = atomicCAS(ctl + 1, head, head + 1u);
+                if (seen != head) {
+                    head = seen;
+                    continue;
+                }
+                // entry `head` is this wave's; its writer reserved it a moment ago (if it is late the block stays with the queue)
+                unsigned b = ~0u;
+                for (int spin = 0; spin < 4096 && (b = sched_load(list + head)) == ~0u; spin++) __builtin_amdgcn_s_sleep(1);
+                if (b != ~0u && sched_claim(job, b)) return b;
+                head++;
+            }
+        }
+        const unsigned long long q = atomicAdd(job.queue_head, 1ull);
+        if (q >= n_blocks) return ~0u;
+        const unsigned b = static_cast<unsigned>(q);
+        if (b < job.n_groups || sched_claim(job, b)) return b;      // first samples have no other way
+    }
+}
+// fetch_ids for launches with DevJob::sched.  The block in hand belongs to the WORKGROUP (`hand`, a word of its LDS:
+// next id << 24 | ids left, kHandBusy while one wave is away fetching the next block, kHandDry once there is none): a
+// context dies only when no id is left anywhere, whichever shader wave it asks — with a hand per wave the contexts could
+// all die through the wave whose hand is empty while the other wave's still holds ids.
+constexpr unsigned long long kHandBusy = ~0ull, kHandDry = ~0ull - 1ull;
+constexpr unsigned long long kStuckTicksEarly = 100000000ull;   // = kStuckTicks (1 s of the 100 MHz clock)
+RT_DEV bool fetch_ids_scheduled(const DevJob& job, unsigned long long* hand, unsigned* abort_flag, bool need, unsigned long long& id) {
+    const unsigned long long mask = __ballot(need);
+    if (mask == 0ull) return false;
+    const int lane = threadIdx.x & 63;
+    const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
+    const unsigned cnt = __popcll(mask);
+    unsigned served = 0;
+    bool got = false;
+    while (served < cnt) {
+        unsigned long long first = 0;
+        unsigned take = 0;
+        if (lane == 0) {
+            unsigned long long t0 = 0;
+            for (;;) {
+                unsigned long long h = __hip_atomic_load(hand, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (h == kHandDry) break;
+                if (h == kHandBusy) {
+                    // (the other wave is fetching: a few microseconds; bounded like every wait of this kernel)
+                    __builtin_amdgcn_s_sleep(2);
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    if (t0 == 0) t0 = now;
+                    if (now - t0 > kStuckTicksEarly) {
+                        __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        break;
+                    }
+                    continue;
+                }
+                const unsigned left = static_cast<unsigned>(h & 0xffffffull);
+                if (left == 0u) {
+                    if (!__hip_atomic_compare_exchange_strong(hand, &h, kHandBusy, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) continue;
+                    const unsigned b = sched_next_block(job);
+                    const unsigned long long per_block = 64ull * job.group_tiles;
+                    __hip_atomic_store(hand, b == ~0u ? kHandDry : ((static_cast<unsigned long long>(b) * per_block) << 24) | per_block, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    continue;
+                }
+                const unsigned want = cnt - served;
+                const unsigned n = left < want ? left : want;
+                const unsigned long long next = h >> 24;
+                if (__hip_atomic_compare_exchange_strong(hand, &h, ((next + n) << 24) | (left - n), __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    first = next;
+                    take = n;
+                    break;
+                }
+            }
+        }
+        first = __shfl(first, 0);
+        take = __shfl(take, 0);
+        if (take == 0u) break;      // dry (or given up)
+        if (need && rank >= served && rank < served + take) {
+            id = first + (rank - served);
+            got = true;
+        }
+        served += take;
+    }
+    return got;
+}
+// A march of the sample in out_slot has just taken step number DevJob::hot_steps << level (marcher waves).
+RT_DEV void sched_mark_hot(const DevScene& sc, const DevJob& job, unsigned long long out_slot, unsigned level) {
+    if (out_slot >= job.n_pixels) return;                        // not a first sample
+    const unsigned pixel = static_cast<unsigned>(out_slot);
+    const unsigned yc = pixel / sc.width, x = pixel % sc.width;
+    const unsigned tile = ((yc >> 3) * job.tiles_x + (x >> 3)) / job.group_tiles;       // its group of tiles, that is
+    if (atomicMax(job.sched + kSchedHeaderWords + tile, level + 1u) >= level + 1u) return;   // on this list, or a higher one, already
+    const unsigned k = job.samples_per_pixel - 1u;
+    uint32_t* const list = sched_list(job, level);
+    const unsigned at = atomicAdd(job.sched + 2 * level, k);
+    for (unsigned s = 1; s <= k; s++) __hip_atomic_store(list + at + (s - 1u), s * job.n_groups + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the level whose threshold `jstep` has just reached, or -1
+RT_DEV int sched_level_reached(const DevJob& job, unsigned jstep) {
+    if (job.hot_steps == 0u) return -1;
+    for (unsigned k = 0; k < kSchedLevels; k++)
+        if (jstep == job.hot_steps << k) return static_cast<int>(k);
+    return -1;
+}
+
 RT_DEV unsigned hash_u32(unsigned x) {
     x ^= x >> 16;
     x *= 0x7feb352dU;
@@ -601,8 +746,18 @@ RT_DEV unsigned hash_u32(unsigned x) {
 RT_DEV bool start_sample(const DevScene& sc, const DevJob& job, unsigned long long id, Lane& L) {
     const unsigned p = static_cast<unsigned>(id & 63ull);
     const unsigned long long q = id >> 6;
-    const unsigned s = static_cast<unsigned>(q % job.samples_per_pixel);
-    const unsigned tile = static_cast<unsigned>(q / job.samples_per_pixel);
+    // blocks of 64 ids: tile-major (every sample of a tile, then the next tile), or sample-major under DevJob::sched
+    unsigned s, tile;
+    if (job.sched != nullptr) {
+        // block = (sample, group of group_tiles consecutive tiles): sample-major
+        const unsigned long long blk = q / job.group_tiles;
+        s = static_cast<unsigned>(blk / job.n_groups);
+        tile = static_cast<unsigned>(blk % job.n_groups) * job.group_tiles + static_cast<unsigned>(q % job.group_tiles);
+        if (tile >= job.n_tiles) return false;     // padding of the last group
+    } else {
+        s = static_cast<unsigned>(q % job.samples_per_pixel);
+        tile = static_cast<unsigned>(q / job.samples_per_pixel);
+    }
     const unsigned x = (tile % job.tiles_x) * 8 + (p & 7), yc = (tile / job.tiles_x) * 8 + (p >> 3);
     if (x >= sc.width || yc >= job.compact_rows) return false;
     const unsigned y = (job.first_band + (yc / job.band_rows) * job.band_stride) * job.band_rows + yc % job.band_rows;
@@ -623,6 +778,7 @@ RT_DEV bool start_sample(const DevScene& sc, const DevJob& job, unsigned long lo
     origin = {origin.x + lx, origin.y + ly, origin.z};
     L.sp = 0;
     L.resident = 0;
+    L.hot = 0u;
     L.hue = sc.dispersion ? static_cast<int>(hue) : -1;
     L.wavelength = sc.dispersion ? (static_cast<float>(hue) * 45.0f) / 180.0f - 1.0f : 0.0f;
     L.out_slot = static_cast<unsigned long long>(s) * job.n_pixels + static_cast<unsigned long long>(yc) * sc.width + x;
@@ -1141,6 +1297,12 @@ __global__ __launch_bounds__(256, DENSE ? 4 : RT_TRACE_WAVES_PER_SIMD) void trac
 //     converged jobs are finished (6-tap normal, world-space hit) 64 at a time from the NORMAL ring.
 // One workgroup per CU; queues, contexts and results never leave LDS.
 constexpr int kPoolCtx = RT_JULIA_POOL;                       // contexts per workgroup
+#ifndef RT_JULIA_HELPERS
+#define RT_JULIA_HELPERS 64             // contexts set aside for the shadow rays that long samples send out in parallel (a multiple of 32; 0: none)
+#endif
+constexpr int kHelperCtx = RT_JULIA_HELPERS;                  // the last kHelperCtx contexts of the pool
+constexpr int kSampleCtx = kPoolCtx - kHelperCtx;             // contexts that hold a sample's ray tree
+static_assert(kHelperCtx % 32 == 0 && kHelperCtx < kPoolCtx, "helper contexts");
 constexpr int kJuliaConstTable = 16;                          // Julia sets whose constants the workgroup keeps in LDS
 constexpr int kCtxWords = 40;
 constexpr unsigned kJuliaQueueCap = 1024u;                    // a context is on at most one ring
@@ -1174,7 +1336,14 @@ enum CtxWord : int {
     CW_UNION = 16,                                           // 20 words: best hit so far (trace query) or the shaded node (shadow query)
     CW_SLOT_LO = 36, CW_SLOT_HI = 37, CW_MISC = 38, CW_JIDX = 39
 };
-enum CtxFlag : unsigned { CF_KIND_MASK = 3u, CF_QACTIVE = 4u, CF_BLOCKED = 8u, CF_FOUND = 16u, CF_WAITING = 32u, CF_FRESH = 64u };
+enum CtxFlag : unsigned { CF_KIND_MASK = 3u, CF_QACTIVE = 4u, CF_BLOCKED = 8u, CF_FOUND = 16u, CF_WAITING = 32u, CF_FRESH = 64u,
+                          CF_HELPER = 128u /* a shadow ray sent out on behalf of context CW_SLOT_LO & 0xffff, light CW_SLOT_LO >> 16 */,
+                          CF_NEWQUERY = 256u /* ... that has not met the scene yet */ };
+// The join word of a context (CW_JOIN, free in both uses of the union words): bit j = light j's shadow ray is with a helper,
+// bit 8 + j = its answer is in, bit 16 + j = blocked, bit 24 + j = the context is parked until that answer comes.
+constexpr int CW_JOIN = 16 + 19;
+constexpr unsigned kMaxForkLights = 8u;
+constexpr unsigned kCtxHotBit = 16u;      // in CW_MISC: Lane::hot
 enum JobStatus : unsigned { JOB_PENDING = 0u, JOB_MISS = 1u, JOB_HIT = 2u };
 enum RingId : int { R_MARCH = 0, R_NORMAL = 1, R_READY_T = 2, R_READY_S = 3, R_TAIL = 4, R_COUNT = RT_JULIA_TAIL_RING ? 5 : 4 };
 
@@ -1194,6 +1363,8 @@ struct PoolShared {
     unsigned abort;
     unsigned heartbeat;     // bumped by every wave that made progress (watchdog)
     unsigned pad;
+    unsigned helper_free[kHelperCtx / 32 + 1];   // bit b of word w: helper context kSampleCtx + 32 w + b is free
+    __attribute__((aligned(8))) unsigned long long hand;   // fetch_ids_scheduled: the workgroup's block of sample ids
     __attribute__((aligned(16))) float jconst[kJuliaConstTable][8];   // c (4 floats) and the cut plane of the scene's first Julia sets
     JuliaRing ring[R_COUNT];
     __attribute__((aligned(16))) float ctx[kPoolCtx][kCtxWords];
@@ -1306,9 +1477,9 @@ RT_DEV void ctx_put(float* c, int w, F4 v) { *reinterpret_cast<F4*>(c + w) = v; 
 
 // Context -> lane.  `kind` is the ring's kind: the union words hold the best hit of a trace query or the node of a
 // shadow query.
-RT_DEV void ctx_load(const DevScene& sc, const float* c, Lane& L, bool& fresh, unsigned& jstatus, HitRec& jhit) {
+RT_DEV void ctx_load(const DevScene& sc, const float* c, Lane& L, bool& fresh, unsigned& jstatus, HitRec& jhit, unsigned& flags) {
     const F4 a = ctx_get(c, CW_QO), b = ctx_get(c, CW_QD), jr0 = ctx_get(c, CW_JP), jr1 = ctx_get(c, CW_JD), t = ctx_get(c, CW_SLOT_LO);
-    const unsigned flags = __float_as_uint(b.w);
+    flags = __float_as_uint(b.w);
     L.qo = v3(a.x, a.y, a.z);
     L.qmax = a.w;
     L.qd = v3(b.x, b.y, b.z);
@@ -1327,6 +1498,7 @@ RT_DEV void ctx_load(const DevScene& sc, const float* c, Lane& L, bool& fresh, u
     L.out_slot = static_cast<unsigned long long>(__float_as_uint(t.x)) | (static_cast<unsigned long long>(__float_as_uint(t.y)) << 32);
     const unsigned misc = __float_as_uint(t.z);
     L.hue = static_cast<int>(misc & 15u) - 1;
+    L.hot = (misc & kCtxHotBit) != 0u ? 1u : 0u;
     L.sp = (misc >> 8) & 255u;
     L.li = misc >> 16;
     L.wavelength = L.hue >= 0 ? (static_cast<float>(L.hue) * 45.0f) / 180.0f - 1.0f : 0.0f;   // as start_sample
@@ -1360,7 +1532,7 @@ RT_DEV void ctx_load(const DevScene& sc, const float* c, Lane& L, bool& fresh, u
 // ctx_store_cold (before the loop): the sample's words, the shaded node of a shadow query, and the best record of a
 // trace query that does not run the loop in this batch (`keeps_best`: it moves on to the next Julia set).
 RT_DEV void ctx_store_cold(float* c, const Lane& L, bool keeps_best) {
-    const unsigned misc = static_cast<unsigned>(L.hue + 1) | (L.sp << 8) | (L.li << 16);
+    const unsigned misc = static_cast<unsigned>(L.hue + 1) | (L.hot != 0u ? kCtxHotBit : 0u) | (L.sp << 8) | (L.li << 16);
     c[CW_SLOT_LO] = __uint_as_float(static_cast<unsigned>(L.out_slot));
     c[CW_SLOT_HI] = __uint_as_float(static_cast<unsigned>(L.out_slot >> 32));
     c[CW_MISC] = __uint_as_float(misc);
@@ -1369,7 +1541,9 @@ RT_DEV void ctx_store_cold(float* c, const Lane& L, bool keeps_best) {
         ctx_put(c, CW_UNION + 4, F4{L.n_normal.x, L.n_normal.y, L.n_normal.z, __uint_as_float(L.n_obj)});
         ctx_put(c, CW_UNION + 8, F4{L.n_dir.x, L.n_dir.y, L.n_dir.z, L.n_ph.x});
         ctx_put(c, CW_UNION + 12, F4{L.matcol[0], L.matcol[1], L.matcol[2], L.n_ph.y});
-        ctx_put(c, CW_UNION + 16, F4{L.acc[0], L.acc[1], L.acc[2], 0.0f});
+        c[CW_UNION + 16] = L.acc[0];       // (not the fourth word: CW_JOIN, which helpers write)
+        c[CW_UNION + 17] = L.acc[1];
+        c[CW_UNION + 18] = L.acc[2];
     } else if (keeps_best) {
         c[CW_UNION + 6] = L.best.uv.x;
         c[CW_UNION + 7] = L.best.uv.y;
@@ -1380,8 +1554,9 @@ RT_DEV void ctx_store_cold(float* c, const Lane& L, bool keeps_best) {
 // The HitSink of a context: accept_hit writes the record of a trace query's winner straight into the union words.
 RT_DEV HitSink ctx_hit_sink(float* c) { return {c, 1u, CW_UNION + 8, CW_UNION + 12, CW_UNION + 6, CW_UNION + 11, CW_UNION + 15}; }
 // ctx_store_hot (after the loop): the query and its state (waiting: a Julia job goes with it).
-RT_DEV void ctx_store_hot(float* c, const Lane& L, bool waiting) {
+RT_DEV void ctx_store_hot(float* c, const Lane& L, bool waiting, bool helper = false) {
     unsigned flags = static_cast<unsigned>(L.qkind) & CF_KIND_MASK;
+    if (helper) flags |= CF_HELPER;
     if (L.qactive) flags |= CF_QACTIVE;
     if (L.blocked) flags |= CF_BLOCKED;
     if (L.found) flags |= CF_FOUND;
@@ -1402,7 +1577,7 @@ RT_DEV void ctx_store_hot(float* c, const Lane& L, bool waiting) {
 
 // ---- marcher waves ------------------------------------------------------------------------------------------
 template <bool STATS>
-RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n, unsigned long long* counter_words) {
+RT_DEV void julia_marcher(const DevScene& sc, const DevJob& job, PoolShared& sh, Counters& n, unsigned long long* counter_words) {
     const int lane = threadIdx.x & 63;
     bool has = false, busy = false;
     unsigned owner = 0, jidx = 0, jstep = 0, it = 0, okind = 0, prev_it = 0;
@@ -1518,7 +1693,7 @@ RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n, unsig
             }
             const int n_now = __popcll(__ballot(has));
             if (n_now == 0) {
-                if (flags.x >= static_cast<unsigned>(kPoolCtx)) break;     // every context is dead: no job can come any more
+                if (flags.x >= static_cast<unsigned>(kSampleCtx)) break;   // every sample context is dead: no job can come any more
                 idle_wait(sh, watch);
                 charge(D_M_IDLE_CYCLES);
                 continue;
@@ -1572,6 +1747,18 @@ RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n, unsig
                 prev_it = it;
             }
             const int r = julia_advance(julia_distance_tail_march(s.m2, s.d2), p, d, jstep);
+            const int hot_level = r == 0 ? sched_level_reached(job, jstep) : -1;
+            if (hot_level >= 0) {
+                // a long march: the sample is hot from here on (julia_shader sends its shadow rays out in parallel), and
+                // so is its tile (the tile's other samples jump the queue)
+                float* c = sh.ctx[owner];
+                if ((__float_as_uint(c[CW_FLAGS]) & CF_HELPER) == 0u) {
+                    c[CW_MISC] = __uint_as_float(__float_as_uint(c[CW_MISC]) | kCtxHotBit);
+                    if (job.sched != nullptr)
+                        sched_mark_hot(sc, job, static_cast<unsigned long long>(__float_as_uint(c[CW_SLOT_LO])) | (static_cast<unsigned long long>(__float_as_uint(c[CW_SLOT_HI])) << 32),
+                                       static_cast<unsigned>(hot_level));
+                }
+            }
             if (r == 0) {
                 s = julia_pk_begin({p.x, p.y, p.z, cut});
                 it = 0;
@@ -1596,6 +1783,265 @@ RT_DEV void julia_marcher(const DevScene& sc, PoolShared& sh, Counters& n, unsig
         ring_push(sh.ring[R_READY_S], &sh.ctl[2 * R_READY_S + 1], miss_s, owner);
         beat(sh);
         charge(D_M_TAIL_CYCLES);
+    }
+    if (TIMED) wc.flush(counter_words);
+}
+
+// ---- marcher waves with two jobs per lane (RT_JULIA_DUAL, the default) ---------------------------------------------
+// julia_marcher above takes the march steps of a wave's lanes together once 5/8 of them have an estimate complete:
+// measured on C4, 35 of the 51 lanes that hold a job run the estimator and 37 lanes take a step, because estimates of
+// one wave end one to sixteen blocks apart and a lane that is done idles until the wave's step phase.  Here a lane
+// holds up to TWO jobs but only ONE estimator state:
+//   E  the job being estimated (registers: the packed quaternion state);
+//   Q  a second job that is either PENDING (its estimate is complete: (m2, d2) kept in two registers, its march step
+//      due) or READY (its position after the step, three registers: the estimate can start at once).
+// A lane whose estimate completes parks it in Q and goes on with the job that was READY there, so it idles only when
+// both of its jobs wait for a step; the wave takes the steps of all PENDING jobs together once RT_JULIA_DUAL_PENDING
+// lanes have one (or RT_JULIA_DUAL_STALLED_EIGHTHS of the lanes that hold a job have nothing else to do).  What a step needs besides (m2, d2)
+// — position, direction, step count — stays in the job's context record in LDS (CW_JP, CW_JD; the step count in
+// CW_JDIST, which is free while the job marches) and is read and written in the step phase only.
+#ifndef RT_JULIA_DUAL_PENDING
+#define RT_JULIA_DUAL_PENDING 48
+#endif
+#ifndef RT_JULIA_DUAL_STALLED_EIGHTHS
+#define RT_JULIA_DUAL_STALLED_EIGHTHS 4  // ... or this many eighths of the lanes that hold a job wait for it
+#endif
+#ifndef RT_JULIA_DUAL_REFILL
+#define RT_JULIA_DUAL_REFILL 8          // empty Q slots that make a wave look at the MARCH ring
+#endif
+template <bool STATS>
+RT_DEV void julia_marcher_dual(const DevScene& sc, const DevJob& job, PoolShared& sh, Counters& n, unsigned long long* counter_words) {
+    const int lane = threadIdx.x & 63;
+    enum : unsigned { E_NONE = 0u, E_RUN = 1u, E_DONE = 2u, Q_EMPTY = 0u, Q_READY = 1u, Q_PENDING = 2u };
+    unsigned e_state = E_NONE, q_state = Q_EMPTY;
+    unsigned owner_e = 0, owner_q = 0;          // context id | Julia set index << 16
+    unsigned it = 0, q_it = 0, cjidx = ~0u;
+    float qa = 0.0f, qb = 0.0f, qc = 0.0f;      // PENDING: m2, d2;  READY: the position
+    JuliaPk s = julia_pk_begin({0, 0, 0, 0});
+    PkF2 cp = {0, 0}, cq = {0, 0};
+    float cut = 0.0f;
+    IdleWatch watch = {0u, 0ull, false, 0ull, 0u};
+    long long t_mark = STATS ? clock64() : 0;
+    constexpr bool TIMED = kPhaseTiming && !STATS;
+    WaveClocks wc;
+    enum { W_MARCH, W_TAIL, W_REFILL, W_IDLE, W_NORMAL, W_PHASES, W_LANES, W_BLOCKS, W_TAIL_LANES, W_NORMAL_PHASES, W_NORMAL_LANES, W_BUSY_LANES };
+    if (TIMED) {
+        const int slots[] = {D_MARCH_CYCLES, D_M_TAIL_CYCLES, D_M_REFILL_CYCLES, D_M_IDLE_CYCLES, D_NORMAL_CYCLES, D_MARCH_PHASES, D_MARCH_LANES,
+                             D_DE_WAVE_ITERS, D_M_TAIL_LANES, D_NORMAL_PHASES, D_NORMAL_LANES, D_MARCH_HAS_SUM};
+        wc.begin(slots, 12);
+    }
+    auto charge = [&](int slot) {
+        if (STATS) {
+            const long long now = clock64();
+            if (lane == 0) n.v[slot] += static_cast<unsigned long long>(now - t_mark);
+            t_mark = now;
+        } else if (TIMED) {
+            wc.charge(slot == D_MARCH_CYCLES ? W_MARCH : slot == D_M_TAIL_CYCLES ? W_TAIL : slot == D_M_REFILL_CYCLES ? W_REFILL : slot == D_M_IDLE_CYCLES ? W_IDLE : W_NORMAL);
+        }
+    };
+    auto load_constants = [&](unsigned jidx) {
+        if (jidx < static_cast<unsigned>(kJuliaConstTable)) {
+            const F4 c4 = *reinterpret_cast<const F4*>(sh.jconst[jidx]);
+            cp = {c4.x, c4.y};
+            cq = {c4.z, c4.w};
+            cut = sh.jconst[jidx][4];
+        } else {
+            const DevJulia& j = sc.julias[jidx];
+            cp = {j.c[0], j.c[1]};
+            cq = {j.c[2], j.c[3]};
+            cut = j.cut_plane;
+        }
+        cjidx = jidx;
+    };
+    unsigned round = 0;
+    for (;;) {
+        const int n_empty = __popcll(__ballot(q_state == Q_EMPTY));
+        round++;
+        if (n_empty >= RT_JULIA_DUAL_REFILL || (round & 7u) == 0u) {
+            typedef unsigned U4 __attribute__((ext_vector_type(4)));
+            const U4 ctl = *reinterpret_cast<volatile U4*>(sh.ctl);                  // march head, tail, normal head, tail
+            const U4 flags = *reinterpret_cast<volatile U4*>(&sh.dead);              // dead, abort, heartbeat
+            if (flags.y != 0u) break;
+            const unsigned n_conv = ctl.w - ctl.z, n_jobs = ctl.y - ctl.x;
+            const int n_held = __popcll(__ballot(e_state != E_NONE)) + (64 - n_empty);
+            if (STATS && lane == 0) {
+                n.v[D_MARCH_POLLS]++;
+                n.v[D_MARCH_HAS_SUM] += static_cast<unsigned long long>(n_held);
+            }
+            // ---- finish converged jobs: a full batch at once, a partial one when there is little else to do
+            if (n_conv >= 64u || (n_conv > 0u && n_held < RT_JULIA_NORMAL_IDLE && n_jobs == 0u)) {
+                unsigned first = 0;
+                const unsigned got = ring_pop(&sh.ctl[2 * R_NORMAL], &sh.ctl[2 * R_NORMAL + 1], 64u, first);
+                bool to_t = false, to_s = false;
+                unsigned o = 0;
+                if (static_cast<unsigned>(lane) < got) {
+                    o = ring_entry(sh.ring[R_NORMAL], first + lane, &sh.abort);
+                    float* c = sh.ctx[o];
+                    const F4 q0 = ctx_get(c, CW_QO), q1 = ctx_get(c, CW_QD), j0 = ctx_get(c, CW_JP), j1 = ctx_get(c, CW_JD);
+                    const DevJulia& j = sc.julias[__float_as_uint(c[CW_JIDX])];
+                    bump<STATS>(n, C_JULIA_NORMALS);
+                    unsigned long long iters = 0;
+                    HitRec h;
+                    // the distance limits of src/objects.cpp:236 are applied by the shader wave (it knows the query)
+                    const bool hit = julia_finish<STATS>(j, v3(q0.x, q0.y, q0.z), v3(j0.x, j0.y, j0.z), v3(j1.x, j1.y, j1.z), kInfinite, h, iters);
+                    bump<STATS>(n, C_JULIA_DE_ITERATIONS, iters);
+                    if (hit) {
+                        ctx_put(c, CW_JP, F4{h.point.x, h.point.y, h.point.z, h.dist});
+                        ctx_put(c, CW_JD, F4{h.normal.x, h.normal.y, h.normal.z, __uint_as_float(JOB_HIT)});
+                    } else {
+                        c[CW_JSTATUS] = __uint_as_float(JOB_MISS);
+                    }
+                    const bool shadow = (__float_as_uint(q1.w) & CF_KIND_MASK) == static_cast<unsigned>(Q_SHADOW);
+                    to_s = shadow;
+                    to_t = !shadow;
+                }
+                ring_push(sh.ring[R_READY_T], &sh.ctl[2 * R_READY_T + 1], to_t, o);
+                ring_push(sh.ring[R_READY_S], &sh.ctl[2 * R_READY_S + 1], to_s, o);
+                beat(sh);
+                if (STATS && lane == 0) n.v[D_NORMAL_PHASES]++;
+                if (STATS && static_cast<unsigned>(lane) < got) n.v[D_NORMAL_LANES]++;
+                if (TIMED) {
+                    wc.add(W_NORMAL_PHASES, 1);
+                    wc.add(W_NORMAL_LANES, got);
+                }
+                charge(D_NORMAL_CYCLES);
+                continue;
+            }
+            // ---- new jobs from the march ring into empty Q slots: READY at once (the shader wave left the entry position)
+            const unsigned long long need = __ballot(q_state == Q_EMPTY);
+            if (need != 0ull && n_jobs != 0u) {
+                unsigned first = 0;
+                const unsigned got = ring_pop(&sh.ctl[2 * R_MARCH], &sh.ctl[2 * R_MARCH + 1], static_cast<unsigned>(__popcll(need)), first);
+                const unsigned rank = __popcll(need & ((1ull << lane) - 1ull));
+                if (q_state == Q_EMPTY && rank < got) {
+                    const unsigned o = ring_entry(sh.ring[R_MARCH], first + rank, &sh.abort);
+                    const float* c = sh.ctx[o];
+                    const F4 j0 = ctx_get(c, CW_JP);
+                    owner_q = o | (__float_as_uint(c[CW_JIDX]) << 16);
+                    qa = j0.x;
+                    qb = j0.y;
+                    qc = j0.z;
+                    q_state = Q_READY;
+                }
+            }
+            if (!__any(e_state != E_NONE || q_state != Q_EMPTY)) {
+                if (flags.x >= static_cast<unsigned>(kSampleCtx)) break;   // every sample context is dead: no job can come any more
+                idle_wait(sh, watch);
+                charge(D_M_IDLE_CYCLES);
+                continue;
+            }
+        }
+        watch.armed = false;
+        // ---- a complete estimate moves to Q (PENDING) unless Q holds one already; a READY job becomes the lane's estimate
+        {
+            const bool start = e_state != E_RUN && q_state == Q_READY;
+            const bool park = e_state == E_DONE && q_state != Q_PENDING;
+            const unsigned was_e = owner_e, was_it = it;
+            const float m2 = s.m2, d2 = s.d2;
+            if (__any(start)) {
+                if (__any(start && (owner_q >> 16) != cjidx)) {
+                    if (start && (owner_q >> 16) != cjidx) load_constants(owner_q >> 16);
+                }
+                if (start) {
+                    owner_e = owner_q;
+                    s = julia_pk_begin({qa, qb, qc, cut});
+                    it = 0;
+                    e_state = E_RUN;
+                    q_state = Q_EMPTY;
+                }
+            }
+            if (park) {
+                owner_q = was_e;
+                qa = m2;
+                qb = d2;
+                q_it = was_it;
+                q_state = Q_PENDING;
+                if (!start) e_state = E_NONE;
+            }
+        }
+        const int n_run = __popcll(__ballot(e_state == E_RUN)), n_pend = __popcll(__ballot(q_state == Q_PENDING));
+        const int n_stalled = __popcll(__ballot(e_state != E_RUN && q_state == Q_PENDING));   // lanes that wait for the step phase
+        charge(D_M_REFILL_CYCLES);
+        if (n_pend >= RT_JULIA_DUAL_PENDING || (n_pend > 0 && n_stalled * 8 >= (n_run + n_stalled) * RT_JULIA_DUAL_STALLED_EIGHTHS)) {
+            // ---- march steps of the PENDING jobs (src/objects.cpp:206-221)
+            if (STATS && lane == 0) n.v[D_M_TAIL_BLOCKS]++;
+            if (STATS && q_state == Q_PENDING) n.v[D_M_TAIL_LANES]++;
+            if (TIMED) {
+                wc.add(W_PHASES, 1);
+                wc.add(W_TAIL_LANES, static_cast<unsigned>(n_pend));
+            }
+            if (STATS && lane == 0) n.v[D_MARCH_PHASES]++;
+            bool converged = false, miss_t = false, miss_s = false;
+            const unsigned o = owner_q & 0xffffu;
+            if (q_state == Q_PENDING) {
+                bump<STATS>(n, C_JULIA_STEPS);
+                if (STATS) {
+                    const int b = q_it <= 1u ? 0 : q_it <= 2u ? 1 : q_it <= 4u ? 2 : q_it <= 8u ? 3 : q_it <= 16u ? 4 : q_it <= 32u ? 5 : 6;
+                    n.v[D_STEP_BLOCKS_1 + b]++;
+                    n.v[D_STEP_BLOCK_SUM] += q_it;
+                }
+                float* c = sh.ctx[o];
+                const F4 j0 = ctx_get(c, CW_JP), j1 = ctx_get(c, CW_JD);
+                V3 p = v3(j0.x, j0.y, j0.z);
+                unsigned jstep = __float_as_uint(j0.w);
+                const int r = julia_advance(julia_distance_tail_march(qa, qb), p, v3(j1.x, j1.y, j1.z), jstep);
+                const int hot_level = r == 0 ? sched_level_reached(job, jstep) : -1;
+                if (hot_level >= 0 && (__float_as_uint(c[CW_FLAGS]) & CF_HELPER) == 0u) {
+                    c[CW_MISC] = __uint_as_float(__float_as_uint(c[CW_MISC]) | kCtxHotBit);
+                    if (job.sched != nullptr)
+                        sched_mark_hot(sc, job, static_cast<unsigned long long>(__float_as_uint(c[CW_SLOT_LO])) | (static_cast<unsigned long long>(__float_as_uint(c[CW_SLOT_HI])) << 32),
+                                       static_cast<unsigned>(hot_level));
+                }
+                if (r == 0) {
+                    ctx_put(c, CW_JP, F4{p.x, p.y, p.z, __uint_as_float(jstep)});
+                    qa = p.x;
+                    qb = p.y;
+                    qc = p.z;
+                    q_state = Q_READY;
+                } else {
+                    q_state = Q_EMPTY;
+                    if (r == 1) {
+                        converged = true;
+                        c[CW_JP] = p.x;
+                        c[CW_JP + 1] = p.y;
+                        c[CW_JP + 2] = p.z;
+                    } else {
+                        c[CW_JSTATUS] = __uint_as_float(JOB_MISS);
+                        miss_s = (__float_as_uint(c[CW_FLAGS]) & CF_KIND_MASK) == static_cast<unsigned>(Q_SHADOW);
+                        miss_t = !miss_s;
+                    }
+                }
+            }
+            ring_push(sh.ring[R_NORMAL], &sh.ctl[2 * R_NORMAL + 1], converged, o);
+            ring_push(sh.ring[R_READY_T], &sh.ctl[2 * R_READY_T + 1], miss_t, o);
+            ring_push(sh.ring[R_READY_S], &sh.ctl[2 * R_READY_S + 1], miss_s, o);
+            beat(sh);
+            charge(D_M_TAIL_CYCLES);
+            continue;
+        }
+        if (n_run == 0) continue;     // (nothing to estimate and no step due: only READY jobs of lanes that start them next round)
+        // ---- one estimator block of four passes
+        if (e_state == E_RUN) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                bump<STATS>(n, C_JULIA_DE_ITERATIONS);
+                julia_pk_iterate_only(s, cp, cq);
+                // (the counters build stops where the oracle's count stops: at the overflow of d2 itself)
+                if (s.m2 > 1e10f || (STATS && s.d2 == __builtin_inff())) break;
+            }
+            it++;   // blocks of four
+            // exact early-out once d2 has overflowed, looked at once per block: further iterations
+            // cannot change the value the march uses
+            if (s.m2 > 1e10f || s.d2 == __builtin_inff() || it >= kJuliaDistanceIterations / 4) e_state = E_DONE;
+        }
+        if (STATS && lane == 0) n.v[D_DE_WAVE_ITERS] += 256ull;
+        if (STATS && e_state != E_NONE) n.v[D_MARCH_LANES]++;
+        if (TIMED) {
+            wc.add(W_BLOCKS, 1);
+            wc.add(W_BUSY_LANES, static_cast<unsigned>(n_run));
+            wc.add(W_LANES, static_cast<unsigned>(__popcll(__ballot(e_state != E_NONE || q_state != Q_EMPTY))));
+        }
+        charge(D_MARCH_CYCLES);
     }
     if (TIMED) wc.flush(counter_words);
 }
@@ -1750,7 +2196,7 @@ RT_DEV void julia_marcher_pooled(const DevScene& sc, PoolShared& sh, Counters& n
         }
         const int n_has = __popcll(__ballot(has));
         if (n_has == 0) {
-            if (flags.x >= static_cast<unsigned>(kPoolCtx)) break;     // every context is dead: no job can come any more
+            if (flags.x >= static_cast<unsigned>(kSampleCtx)) break;   // every sample context is dead: no job can come any more
             idle_wait(sh, watch);
             charge(D_M_IDLE_CYCLES);
             continue;
@@ -1828,7 +2274,7 @@ RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob&
         const U4 ctl_m = *reinterpret_cast<volatile U4*>(sh.ctl);             // march head, tail, normal head, tail
         const U4 ctl_r = *reinterpret_cast<volatile U4*>(sh.ctl + 4);         // ready_t head, tail, ready_s head, tail
         const U4 flags = *reinterpret_cast<volatile U4*>(&sh.dead);           // dead, abort, heartbeat
-        if (flags.y != 0u || flags.x >= static_cast<unsigned>(kPoolCtx)) break;
+        if (flags.y != 0u || flags.x >= static_cast<unsigned>(kSampleCtx)) break;
         const unsigned n_t = ctl_r.y - ctl_r.x, n_s = ctl_r.w - ctl_r.z, n_jobs = ctl_m.y - ctl_m.x;
         if (STATS && lane == 0) {
             n.v[D_RING_SAMPLES]++;
@@ -1862,13 +2308,18 @@ RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob&
         L.jidx = 0;
         L.jstep = 0;
         L.qactive = 0u;
-        unsigned id = 0, jstatus = JOB_PENDING;
+        L.hot = 0u;
+        L.li = 0;
+        unsigned id = 0, jstatus = JOB_PENDING, cflags = 0u;
         bool fresh = false;
         HitRec jhit = {};
         if (mine) {
             id = ring_entry(sh.ring[r], first + lane, &sh.abort);
-            ctx_load(sc, sh.ctx[id], L, fresh, jstatus, jhit);
+            ctx_load(sc, sh.ctx[id], L, fresh, jstatus, jhit, cflags);
         }
+        // a helper context: one shadow ray of another context's node (see "shadow rays in parallel" below)
+        const bool helper = mine && (cflags & CF_HELPER) != 0u;
+        if (helper && (cflags & CF_NEWQUERY) != 0u) L.state = S_QUERY;
         if (STATS) {
             if (lane == 0) n.v[D_RESOLVE_PHASES]++;
             if (mine) n.v[D_RESOLVE_LANES]++;
@@ -1899,17 +2350,94 @@ RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob&
                 }
             }
         }
-        // ---- resolve: one step of the ray tree; a finished sample is stored and the context takes the next one
+        // ---- resolve: one step of the ray tree; a finished sample is stored and the context takes the next one.
+        // Shadow rays in parallel: a sample is a chain of dependent queries, and the longest chains set the frame's
+        // time (fetch_ids_scheduled explains).  A HOT sample — one of its marches has reached DevJob::hot_steps — therefore
+        // sends the shadow rays of a node's lights out together: the first one is its own query as always, each further
+        // lit light's ray goes to a free HELPER context, which takes it through the same pipeline and leaves the answer
+        // (blocked or not) in the node's join word.  The node still adds its lights in the reference's order: when it
+        // comes to a light whose ray a helper has, it takes the answer if it is there (and goes on at once) or parks
+        // until the helper wakes it.  Lights are sent out only if resolve_lane will ask for them (same elision rule),
+        // so every helper's answer is consumed before the node moves on.
         bool done = false;
         Col value = {0.0f, 0.0f, 0.0f, 0.0f};
         const FramesInHbm frames = {wg_frames + static_cast<size_t>(id) * (sc.max_bounces + 1) * kFrameRecordWords};
-        if (mine && L.state == S_RESOLVE && !fresh) resolve_lane<STATS>(sc, T, job, frames, L, n, done, value);
+        float* const my_ctx = sh.ctx[mine ? id : 0u];
+        unsigned* const my_join = reinterpret_cast<unsigned*>(my_ctx + CW_JOIN);
+        bool again = mine && L.state == S_RESOLVE && !fresh && !helper;
+        bool first_pass = true;
+        while (__any(again)) {
+            bool fork = false;
+            if (again) {
+                again = false;
+                const bool was_trace = L.qkind == Q_TRACE;
+                resolve_lane<STATS>(sc, T, job, frames, L, n, done, value);
+                if (L.state == S_QUERY && L.qkind == Q_SHADOW) {
+                    if (was_trace) {
+                        fork = !STATS && kHelperCtx > 0 && L.hot != 0u && L.li + 1u < sc.n_lights;
+                        lds_store(my_join, 0u);        // (no helper holds a ray of this context: the last node consumed them all)
+                    } else if (L.li < kMaxForkLights) {
+                        const unsigned jw = lds_load(my_join);
+                        if ((jw >> L.li) & 1u) {
+                            if ((jw >> (8u + L.li)) & 1u) {
+                                L.blocked = (jw >> (16u + L.li)) & 1u;
+                                L.qactive = 0u;
+                                L.state = S_RESOLVE;
+                                again = true;
+                            } else {
+                                L.state = S_PARK;
+                            }
+                        }
+                    }
+                }
+            }
+            if (first_pass && __any(fork)) {
+                // (only a trace result can open a node, so every fork of this batch happens in the first pass)
+                const DevMaterial& m = T.materials[T.object_material[fork ? L.n_obj : 0u]];
+                const bool may_elide = sc.lights_benign != 0u && job.elide_unlit != 0u && fork && m.phong_tame != 0u;
+                const unsigned last = sc.n_lights < kMaxForkLights ? sc.n_lights : kMaxForkLights;
+                for (unsigned j = 1; j < last; j++) {
+                    bool want = fork && j > L.li;
+                    if (want && may_elide) want = skip_dark_lights<false>(T.lights, j + 1u, j, L.n_point, L.n_normal, L.n_dir, m.kd, m.ks, m.exponent, true, n) == j;
+                    unsigned h = ~0u;
+                    if (want) {
+                        // a free helper context (bit set = free), any word
+                        for (unsigned t = 0; t < 2u * (kHelperCtx / 32) && h == ~0u; t++) {
+                            const unsigned w = (static_cast<unsigned>(lane) + t) % (kHelperCtx / 32 > 0 ? kHelperCtx / 32 : 1);
+                            const unsigned v = lds_load(&sh.helper_free[w]);
+                            if (v == 0u) continue;
+                            const unsigned bit = v & (0u - v);
+                            const unsigned old = __hip_atomic_fetch_and(&sh.helper_free[w], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if ((old & bit) != 0u) h = static_cast<unsigned>(kSampleCtx) + w * 32u + static_cast<unsigned>(__ffs(static_cast<int>(bit)) - 1);
+                        }
+                    }
+                    if (h != ~0u) {
+                        Lane ray = L;
+                        ray.li = j;
+                        begin_shadow(T, ray);
+                        float* hc = sh.ctx[h];
+                        ctx_put(hc, CW_QO, F4{ray.qo.x, ray.qo.y, ray.qo.z, ray.qmax});
+                        ctx_put(hc, CW_QD, F4{ray.qd.x, ray.qd.y, ray.qd.z, __uint_as_float(static_cast<unsigned>(Q_SHADOW) | CF_QACTIVE | CF_HELPER | CF_NEWQUERY)});
+                        hc[CW_JSTATUS] = __uint_as_float(JOB_PENDING);
+                        hc[CW_SLOT_LO] = __uint_as_float(id | (j << 16));
+                        hc[CW_SLOT_HI] = __uint_as_float(0u);
+                        hc[CW_MISC] = __uint_as_float(0u);
+                        hc[CW_JIDX] = __uint_as_float(0u);
+                        // the join word says so before the helper can be seen by anyone (ring_push releases)
+                        __hip_atomic_fetch_or(my_join, 1u << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    ring_push(sh.ring[R_READY_S], &sh.ctl[2 * R_READY_S + 1], h != ~0u, h);
+                }
+            }
+            first_pass = false;
+        }
         if (mine && done) store_sample(sc, job, L, value);
         bool need = mine && (fresh || done);
         bool died = false;
         while (__any(need)) {
             unsigned long long sid = 0;
-            const bool got_id = fetch_ids(job.queue_head, job.dyn_base, job.n_samples, job.id_chunk, wave_ids, need, sid);
+            const bool got_id = job.sched != nullptr ? fetch_ids_scheduled(job, &sh.hand, &sh.abort, need, sid)
+                                                     : fetch_ids(job.queue_head, job.dyn_base, job.n_samples, job.id_chunk, wave_ids, need, sid);
             if (need) {
                 if (!got_id) {
                     need = false;       // the queue is exhausted: this context is done for the launch
@@ -1921,8 +2449,24 @@ RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob&
             }
         }
         charge(D_RESOLVE_CYCLES);
-        const bool alive = mine && !died;
-        float* const my_ctx = sh.ctx[mine ? id : 0u];
+        // a helper whose query is complete leaves its answer with the node and is free again
+        const bool deliver = helper && L.state == S_RESOLVE;
+        bool wake = false;
+        unsigned parent = 0;
+        if (deliver) {
+            const unsigned who = __float_as_uint(my_ctx[CW_SLOT_LO]);
+            parent = who & 0xffffu;
+            const unsigned j = who >> 16;
+            float* pc = sh.ctx[parent];
+            const unsigned bits = (1u << (8u + j)) | (L.blocked != 0u ? 1u << (16u + j) : 0u);
+            const unsigned old = __hip_atomic_fetch_or(reinterpret_cast<unsigned*>(pc + CW_JOIN), bits, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            wake = ((old >> (24u + j)) & 1u) != 0u;
+            // (a parked node is nobody's but the helper's that wakes it: its flags word takes the answer)
+            if (wake && L.blocked != 0u) pc[CW_FLAGS] = __uint_as_float(__float_as_uint(pc[CW_FLAGS]) | CF_BLOCKED);
+            const unsigned hid = id - static_cast<unsigned>(kSampleCtx);
+            __hip_atomic_fetch_or(&sh.helper_free[hid >> 5], 1u << (hid & 31u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const bool alive = mine && !died && !deliver;
         if (alive) ctx_store_cold(my_ctx, L, L.state != S_QUERY);
         // ---- the new query against everything that is not a Julia set, then the first set it enters
         if (__any(L.state == S_QUERY)) {
@@ -1953,10 +2497,22 @@ RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob&
             }
         }
         // ---- back into the pool, and on to the next ring
-        if (alive) ctx_store_hot(my_ctx, L, push_job);
+        if (alive) ctx_store_hot(my_ctx, L, push_job, helper);
+        // a node that waits for a helper: parked (on no ring) unless the answer has come in the meantime
+        const bool park = alive && L.state == S_PARK;
+        bool unparked = false;
+        if (park) {
+            lds_release();
+            const unsigned old = __hip_atomic_fetch_or(my_join, 1u << (24u + L.li), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((old >> (8u + L.li)) & 1u) {
+                if ((old >> (16u + L.li)) & 1u) my_ctx[CW_FLAGS] = __uint_as_float(__float_as_uint(my_ctx[CW_FLAGS]) | CF_BLOCKED);
+                unparked = true;
+            }
+        }
         ring_push(sh.ring[R_MARCH], &sh.ctl[2 * R_MARCH + 1], alive && push_job, id);
         ring_push(sh.ring[R_READY_T], &sh.ctl[2 * R_READY_T + 1], alive && !push_job && L.qkind != Q_SHADOW, id);
-        ring_push(sh.ring[R_READY_S], &sh.ctl[2 * R_READY_S + 1], alive && !push_job && L.qkind == Q_SHADOW, id);
+        ring_push(sh.ring[R_READY_S], &sh.ctl[2 * R_READY_S + 1], (alive && !push_job && L.qkind == Q_SHADOW && !park) || unparked, id);
+        ring_push(sh.ring[R_READY_S], &sh.ctl[2 * R_READY_S + 1], wake, parent);
         const unsigned n_died = static_cast<unsigned>(__popcll(__ballot(died)));
         if (n_died != 0u && lane == 0) __hip_atomic_fetch_add(&sh.dead, n_died, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         beat(sh);
@@ -1975,10 +2531,12 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
     for (unsigned i = threadIdx.x; i < kJuliaQueueCap; i += blockDim.x) {
         for (int r = 0; r < R_COUNT; r++) sh.ring[r].slot[i] = 0u;
         // every context starts on READY_T, asking for its first sample
-        if (i < static_cast<unsigned>(kPoolCtx)) {
+        if (i < static_cast<unsigned>(kSampleCtx)) {
             sh.ring[R_READY_T].slot[i] = ring_word(i, i);
             sh.ctx[i][CW_FLAGS] = __uint_as_float(CF_FRESH);
         }
+        if (i < static_cast<unsigned>(kPoolCtx)) sh.ctx[i][CW_JOIN] = __uint_as_float(0u);
+        if (i <= static_cast<unsigned>(kHelperCtx / 32)) sh.helper_free[i] = i < static_cast<unsigned>(kHelperCtx / 32) ? ~0u : 0u;
         if (i < static_cast<unsigned>(kJuliaConstTable) && i < sc.n_julias) {
             for (int k = 0; k < 4; k++) sh.jconst[i][k] = sc.julias[i].c[k];
             sh.jconst[i][4] = sc.julias[i].cut_plane;
@@ -1986,11 +2544,12 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
     }
     if (threadIdx.x == 0) {
         for (int w = 0; w < 12; w++) sh.ctl[w] = 0u;
-        sh.ctl[2 * R_READY_T + 1] = static_cast<unsigned>(kPoolCtx);
+        sh.ctl[2 * R_READY_T + 1] = static_cast<unsigned>(kSampleCtx);
         sh.dead = 0u;
         sh.abort = (job.debug_abort != 0u && blockIdx.x == 0) ? 1u : 0u;   // RT_OPT_DEBUG_FORCE_ABORT
         sh.heartbeat = 0u;
         sh.pad = 0u;
+        sh.hand = 0ull;
     }
     __syncthreads();
     const ShadeTables T = tables_of(sc, sc.shade_blob);
@@ -2000,8 +2559,10 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
     if (wave < kJuliaMarcherWaves) {
 #if RT_JULIA_TAIL_RING
         julia_marcher_pooled<STATS>(sc, sh, n);
+#elif RT_JULIA_DUAL
+        julia_marcher_dual<STATS>(sc, job, sh, n, job.counters);
 #else
-        julia_marcher<STATS>(sc, sh, n, job.counters);
+        julia_marcher<STATS>(sc, job, sh, n, job.counters);
 #endif
     } else {
         const unsigned shader_wave = blockIdx.x * (kJuliaWaves - kJuliaMarcherWaves) + (wave - kJuliaMarcherWaves);

@@ -190,8 +190,22 @@ struct DevJob {
     uint64_t dyn_base;           // first id handed out through queue_head
     uint32_t elide_unlit;        // RT_OPT_ELIDE_UNLIT_SHADOWS and no counters: shadow rays whose light can only add +-0 are not traced
     uint32_t debug_abort;        // RT_OPT_DEBUG_FORCE_ABORT: trace_julia_kernel's first workgroup raises its watchdog flag at once
+    uint32_t n_tiles;            // tiles_x*tiles_y
+    // trace_julia_kernel with samples_per_pixel > 1 (rt_kernels.hip, "long chains first"): ids are handed out in blocks of
+    // group_tiles tiles' worth of one sample, numbered sample-major (block = sample*n_groups + group), one by one through
+    // queue_head; the blocks of groups whose first sample turns out to hold a long Julia march jump the queue through the
+    // hot lists.  Words of `sched` ("tile" below = group of tiles):
+    // [2k] hot entries of level k pushed, [2k + 1] claimed (k < kSchedLevels), [kSchedHeaderWords ..) one word per tile (the
+    // highest level it is on, plus one), then one claim bit per block, then the kSchedLevels hot lists (block numbers, preset
+    // to ~0).  NULL: plain tile-major order, static shares as in trace_kernel.
+    uint32_t* sched;
+    uint32_t hot_steps;          // a march of a first sample that reaches this many steps makes its tile hot
+    uint32_t group_tiles;        // tiles per block under `sched` (a wave's fetch costs three or four round trips to memory: fewer, larger blocks)
+    uint32_t n_groups;           // ceil(n_tiles / group_tiles)
     uint32_t pad0;
 };
+constexpr uint32_t kSchedHeaderWords = 8;
+constexpr uint32_t kSchedLevels = 3;     // a march that reaches hot_steps << k steps puts its tile on list k
 
 // Photon emission job (src/photonmap.cpp:38-57)
 struct DevPhotonJob {
@@ -237,6 +251,9 @@ constexpr uint32_t kDepositLongRun = 32;    // deposits into one texel from whic
 #endif
 #ifndef RT_JULIA_MARCHERS
 #define RT_JULIA_MARCHERS 10
+#endif
+#ifndef RT_JULIA_DUAL
+#define RT_JULIA_DUAL 0             // 1: marcher lanes hold two jobs and one estimator state (rt_kernels.hip: julia_marcher_dual)
 #endif
 #ifndef RT_JULIA_TAIL_RING
 #define RT_JULIA_TAIL_RING 0        // 1: march steps pooled through a fifth ring (rt_kernels.hip: julia_marcher_pooled; measured slower)

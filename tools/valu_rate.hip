@@ -20,6 +20,7 @@
 typedef float F2 __attribute__((ext_vector_type(2)));
 
 constexpr int kUnroll = 16;   // independent chains per lane
+constexpr int kPattern = 66;  // trips of the inner loop for the ordering experiments (a multiple of 22 and 3 ... see KIND 38-41)
 constexpr int kIters = 4096;
 
 template <int KIND>
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, float seed) {
     const double dm = 1.0000001, dc = 1e-9;
     for (int it = 0; it < kIters; it++) {
 #pragma unroll
-        for (int i = 0; i < kUnroll; i++) {
+        for (int i = 0; i < (KIND >= 38 && KIND != 40 ? kPattern : kUnroll); i++) {
             if (KIND == 0) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
             if (KIND == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
             if (KIND == 2) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
@@ -72,6 +73,18 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, float seed) {
             if (KIND == 31) asm volatile("v_cmp_gt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m) : "vcc");
             if (KIND == 32) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
             if (KIND == 33) asm volatile("v_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %2, %0" : "+v"(a[i]) : "v"(m), "s"(seed));   // alternating VGPR / SGPR
+            // ---- ordering experiments: the same mix of "slow" (SGPR operand / compare / max) and "fast" instructions,
+            // grouped (4 slow then 4 fast) or alternating, every instruction on its own chain
+            if (KIND == 34) { if ((i & 7) < 4) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i]) : "s"(seed)); else asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m)); }
+            if (KIND == 35) { if ((i & 1) == 0) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i]) : "s"(seed)); else asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m)); }
+            if (KIND == 36) { if ((i & 7) < 4) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m)); else asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m)); }
+            if (KIND == 37) { if ((i & 1) == 0) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m)); else asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m)); }
+            // the triangle stage's shape as the compiler emits it: s s f  s s f  s s f  s s s s f s s f f f f f f (12 slow, 10 fast) ...
+            if (KIND == 38) { const bool slow = (0xdedb >> (i % 22)) & 1; if (slow) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i % 16]) : "s"(seed)); else asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i % 16]) : "v"(m)); }
+            // ... and the same 12 + 10 alternating as far as the mix allows: s f s f ... s s
+            if (KIND == 39) { const bool slow = (i % 22) >= 20 || ((i % 22) & 1) == 0; if (slow) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i % 16]) : "s"(seed)); else asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i % 16]) : "v"(m)); }
+            if (KIND == 40) { if ((i & 1) == 0) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i]) : "s"(seed)); else asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m)); }   // slow + slow of two kinds
+            if (KIND == 41) { if ((i % 3) == 0) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i % 16]) : "s"(seed)); else asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i % 16]) : "v"(m)); }   // s f f
         }
     }
     float s = 0.0f;
@@ -81,7 +94,7 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, float seed) {
 
 template <int KIND>
 void run(const char* name, float* d_out, int n_cus, double ops_per_instr) {
-    printf("%-28s", name);
+    printf("%-38s", name);
     for (int wps = 1; wps <= 8; wps *= 2) {
         const int blocks = n_cus * wps;   // 256-thread blocks: 4 waves = one per SIMD
         hipEvent_t e0, e1;
@@ -96,7 +109,7 @@ void run(const char* name, float* d_out, int n_cus, double ops_per_instr) {
         float ms = 0;
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         ms /= 3;
-        const double instr_per_simd = static_cast<double>(kIters) * kUnroll * ((KIND == 15 || KIND == 29 || KIND == 31 || KIND == 33) ? 2 : 1) * wps;
+        const double instr_per_simd = static_cast<double>(kIters) * (KIND >= 38 && KIND != 40 ? kPattern : kUnroll) * ((KIND == 15 || KIND == 29 || KIND == 31 || KIND == 33) ? 2 : 1) * wps;
         const double cyc = ms * 1e-3 * 2.4e9 / instr_per_simd;   // cycles at 2.4 GHz per wave-instruction per SIMD
         printf("  w/simd=%d: %6.2f cyc/instr", wps, cyc);
         (void)ops_per_instr;
@@ -145,5 +158,13 @@ int main() {
     run<31>("v_cmp + v_cndmask", d_out, n_cus, 1);
     run<32>("v_xor_b32", d_out, n_cus, 1);
     run<33>("v_mul vgpr, v_mul sgpr", d_out, n_cus, 1);
+    run<34>("4 sgpr-mul, 4 mul grouped", d_out, n_cus, 1);
+    run<35>("sgpr-mul, mul alternating", d_out, n_cus, 1);
+    run<36>("4 max, 4 mul grouped", d_out, n_cus, 1);
+    run<37>("max, mul alternating", d_out, n_cus, 1);
+    run<38>("12 sgpr + 10 plain, compiler's order", d_out, n_cus, 1);
+    run<39>("12 sgpr + 10 plain, alternating", d_out, n_cus, 1);
+    run<40>("sgpr-mul, max alternating", d_out, n_cus, 1);
+    run<41>("sgpr-mul, mul, mul", d_out, n_cus, 1);
     return 0;
 }
