@@ -589,6 +589,8 @@ Col render_pixel(Tracer& tr, const CameraFrame& f, uint32_t x, uint32_t y) {
 }
 
 // ---- photon pass, src/photonmap.cpp --------------------------------------------------------------
+// Diagnostic (oracle_set_deposit_counts): deposits per texel of the pass, [object][y][x] (the photon pass is sequential).
+static uint32_t* g_deposit_counts = nullptr;
 struct PhotonTracer {
     const rt_scene_desc& sc;
     PhotonMaps& maps;
@@ -606,6 +608,7 @@ struct PhotonTracer {
         Col& t = tex[size_t(y) * size + x];
         t = cadd(t, rad);
         geo.n.photon_deposits++;
+        if (g_deposit_counts != nullptr) g_deposit_counts[(size_t(object) * size + y) * size + x]++;
     }
 
     // src/photonmap.cpp:61-146
@@ -927,6 +930,8 @@ uint32_t oracle_pixel_marches(const rt_scene_desc* sc, uint32_t x, uint32_t y, u
     for (uint32_t i = 0; i < log.size() && i < cap; i++) out[i] = log[i];
     return static_cast<uint32_t>(log.size());
 }
+
+void oracle_set_deposit_counts(uint32_t* per_texel) { g_deposit_counts = per_texel; }
 
 // Diagnostic: {steps, iterations, Julia queries} of the sample with the most march steps and of the one with the most
 // estimator iterations since the last call.  Not part of any parity check.

@@ -35,6 +35,9 @@ __global__ void quantize_kernel(const float4* rgba, uchar4* out, float gain, uns
 hipError_t build_triangle_bvh(const DevTriTest* tris, uint32_t first, uint32_t n, DevBvhPair* pairs);
 void build_triangle_bvh_host(const DevTriTest* tris, uint32_t first, uint32_t n, DevBvhPair* pairs);
 hipError_t photon_order_temp_bytes(unsigned capacity, unsigned key_bits, size_t* bytes);
+hipError_t photon_order_bucket(const unsigned long long* keys, const float4* vals, const unsigned* slot, unsigned capacity, unsigned texel_shift, unsigned n_texels,
+                               float4* atlas, unsigned* count, unsigned* seg_first, uint4* runs, unsigned long long* seg_keys, float4* seg_vals,
+                               unsigned* order, unsigned long long* cursor, hipStream_t stream);
 hipError_t photon_order_reduce(const unsigned long long* keys, const float4* vals, unsigned capacity, unsigned key_bits, unsigned texel_shift,
                                unsigned long long n_texels, float4* atlas, unsigned long long* sorted_keys, unsigned* sorted_index,
                                unsigned* long_runs, unsigned long long* words, void* temp, size_t temp_bytes, hipStream_t stream);
@@ -135,10 +138,13 @@ struct rt_ctx {
     bool photon_order = true;          // RT_OPT_PHOTON_ORDER: deposits summed in the reference's order
     // ordered photon deposits (rt_photon_order.hip)
     Buffer dep_keys, dep_vals, dep_sorted_keys, dep_sorted_index, dep_long_runs, dep_temp;
+    Buffer dep_count, dep_seg_first, dep_runs, dep_seg_vals;   // photon_order_bucket: deposits per texel (zero between passes), first record of a texel's segment, run list
+    bool dep_bucket = false;                     // the pass in preparation sums by buckets (atlases below 2^31 texels)
+    bool dep_force_sort = false;                 // RT_PHOTON_ORDER_SORT=1 in the environment: the device-wide sort instead (developer A/B, tests)
     Buffer live_dirs;                            // RT_OPT_CULL_PHOTON_ROOTS: the directions of the photon pass that may meet a specular object
     uint32_t dep_capacity = 0;         // records; 0 = choose from the number of roots
     size_t dep_temp_bytes = 0;
-    unsigned long long* d_dep_words = nullptr;   // [0] records reserved, [1] deposits that found the buffer full, [2] long runs, [3] deposits beyond a root's key field, [4] live directions (photon_cull_kernel)
+    unsigned long long* d_dep_words = nullptr;   // [0] records reserved, [1] deposits that found the buffer full, [2] long runs, [3] deposits beyond a root's key field, [4] live directions (photon_cull_kernel), [5] photon_order_bucket's cursor
     unsigned long long* h_dep_words = nullptr;   // pinned copy, written by the stream after every ordered pass
     hipEvent_t ev_dep = nullptr;
     bool dep_check_pending = false;
@@ -488,7 +494,7 @@ bool deposit_overflow_seen(rt_ctx* ctx) {
     return true;
 }
 
-int deposit_buffers(rt_ctx* ctx, unsigned long long all_roots, unsigned key_bits) {
+int deposit_buffers(rt_ctx* ctx, unsigned long long all_roots, unsigned key_bits, unsigned long long n_texels, hipStream_t stream) {
     (void)deposit_overflow_seen(ctx);
     if (ctx->dep_capacity == 0) {
         // C5: 8.0 M roots leave 0.37 M deposits (+ 0.05 M slots that stay unused: a wave reserves records kDepositChunk at a time)
@@ -501,6 +507,18 @@ int deposit_buffers(rt_ctx* ctx, unsigned long long all_roots, unsigned key_bits
     if ((rc = grow(ctx, ctx->dep_vals, n * sizeof(float4))) != RT_OK) return rc;
     if ((rc = grow(ctx, ctx->dep_sorted_keys, n * sizeof(unsigned long long))) != RT_OK) return rc;
     if ((rc = grow(ctx, ctx->dep_sorted_index, n * sizeof(unsigned))) != RT_OK) return rc;
+    ctx->dep_bucket = n_texels < (1ull << 31) && !ctx->dep_force_sort;
+    if (ctx->dep_bucket) {
+        if ((rc = grow(ctx, ctx->dep_long_runs, n * sizeof(unsigned))) != RT_OK) return rc;     // `order` of photon_order_bucket
+        if ((rc = grow(ctx, ctx->dep_seg_first, n_texels * sizeof(unsigned))) != RT_OK) return rc;
+        if ((rc = grow(ctx, ctx->dep_runs, n * sizeof(uint4))) != RT_OK) return rc;
+        if ((rc = grow(ctx, ctx->dep_seg_vals, n * sizeof(float4))) != RT_OK) return rc;
+        const void* const before = ctx->dep_count.ptr;
+        if ((rc = grow(ctx, ctx->dep_count, n_texels * sizeof(unsigned))) != RT_OK) return rc;
+        // zero once: every pass leaves the counts at zero again (scatter_records_kernel)
+        if (ctx->dep_count.ptr != before) RT_HIP_TRY(ctx, hipMemsetAsync(ctx->dep_count.ptr, 0, ctx->dep_count.bytes, stream));
+        return RT_OK;
+    }
     if ((rc = grow(ctx, ctx->dep_long_runs, (n / kDepositLongRun + 1) * sizeof(unsigned))) != RT_OK) return rc;
     size_t temp = 0;
     RT_HIP_TRY(ctx, photon_order_temp_bytes(ctx->dep_capacity, key_bits, &temp));
@@ -554,6 +572,7 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
         job.queue_head = ctx->d_queue;
         job.counters = ctx->d_counters;
         RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 2 * sizeof(unsigned long long), stream));
+        RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_dep_words, 0, 8 * sizeof(unsigned long long), stream));   // every control word of the pass at once
         // reference deposit order: record, sort, sum (rt_photon_order.hip) when the key fits 64 bits
         const unsigned long long n_texels = static_cast<unsigned long long>(ctx->n_slots) * ctx->dev.photon_size * ctx->dev.photon_size;
         // a root deposits at most once per leaf of its tree, 2^(max_bounces+1) in theory; when the key has no room for
@@ -566,15 +585,16 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
         ctx->dep_last_pass_ordered = ordered;
         ctx->dep_last_pass_overflowed = false;
         if (ordered) {
-            if ((rc = deposit_buffers(ctx, all_roots, key_bits)) != RT_OK) return rc;
+            if ((rc = deposit_buffers(ctx, all_roots, key_bits, n_texels, stream)) != RT_OK) return rc;
             job.dep_keys = static_cast<unsigned long long*>(ctx->dep_keys.ptr);
             job.dep_vals = static_cast<float4*>(ctx->dep_vals.ptr);
             job.dep_words = ctx->d_dep_words;
             job.dep_capacity = ctx->dep_capacity;
+            job.dep_count = ctx->dep_bucket ? static_cast<uint32_t*>(ctx->dep_count.ptr) : nullptr;
+            job.dep_slot = static_cast<uint32_t*>(ctx->dep_sorted_index.ptr);     // (the sort's index array, unused on this path)
             job.dep_seq_bits = seq_bits;
             job.dep_root_bits = root_bits;
             RT_HIP_TRY(ctx, hipMemsetAsync(ctx->dep_keys.ptr, 0xFF, static_cast<size_t>(ctx->dep_capacity) * sizeof(unsigned long long), stream));
-            RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_dep_words, 0, 4 * sizeof(unsigned long long), stream));
         }
         // roots that can leave nothing are dropped before the pass (DevScene::photon_cull_*; not for a slice of the pass,
         // and not under counters: that launch traces every root and checks the claim)
@@ -583,7 +603,6 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
         if (ctx->cull_photon_roots && !stats && n_parts == 1 && ctx->dev.photon_cull_valid != 0u && all_roots < (1ull << 32)) {
             if (ctx->live_dirs.bytes < n_dirs * sizeof(uint32_t)) RT_HIP_TRY(ctx, hipDeviceSynchronize());
             if ((rc = grow(ctx, ctx->live_dirs, n_dirs * sizeof(uint32_t))) != RT_OK) return rc;
-            RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_dep_words + 4, 0, sizeof(unsigned long long), stream));
             hipLaunchKernelGGL(photon_cull_kernel, dim3(static_cast<unsigned>((n_dirs + 255) / 256)), dim3(256), 0, stream, ctx->dev, job,
                                static_cast<unsigned>(n_dirs), static_cast<uint32_t*>(ctx->live_dirs.ptr), ctx->d_dep_words + 4);
             RT_HIP_TRY(ctx, hipGetLastError());
@@ -599,9 +618,15 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
         }
         RT_HIP_TRY(ctx, hipGetLastError());
         if (ordered) {
-            RT_HIP_TRY(ctx, photon_order_reduce(job.dep_keys, job.dep_vals, ctx->dep_capacity, key_bits, root_bits + seq_bits, n_texels, ctx->dev.photon_atlas,
-                                                static_cast<unsigned long long*>(ctx->dep_sorted_keys.ptr), static_cast<unsigned*>(ctx->dep_sorted_index.ptr),
-                                                static_cast<unsigned*>(ctx->dep_long_runs.ptr), ctx->d_dep_words, ctx->dep_temp.ptr, ctx->dep_temp_bytes, stream));
+            if (ctx->dep_bucket)
+                RT_HIP_TRY(ctx, photon_order_bucket(job.dep_keys, job.dep_vals, job.dep_slot, ctx->dep_capacity, root_bits + seq_bits, static_cast<unsigned>(n_texels), ctx->dev.photon_atlas,
+                                                    static_cast<unsigned*>(ctx->dep_count.ptr), static_cast<unsigned*>(ctx->dep_seg_first.ptr), static_cast<uint4*>(ctx->dep_runs.ptr),
+                                                    static_cast<unsigned long long*>(ctx->dep_sorted_keys.ptr), static_cast<float4*>(ctx->dep_seg_vals.ptr),
+                                                    static_cast<unsigned*>(ctx->dep_long_runs.ptr), ctx->d_dep_words + 5, stream));
+            else
+                RT_HIP_TRY(ctx, photon_order_reduce(job.dep_keys, job.dep_vals, ctx->dep_capacity, key_bits, root_bits + seq_bits, n_texels, ctx->dev.photon_atlas,
+                                                    static_cast<unsigned long long*>(ctx->dep_sorted_keys.ptr), static_cast<unsigned*>(ctx->dep_sorted_index.ptr),
+                                                    static_cast<unsigned*>(ctx->dep_long_runs.ptr), ctx->d_dep_words, ctx->dep_temp.ptr, ctx->dep_temp_bytes, stream));
             RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_dep_words, ctx->d_dep_words, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
             RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_dep, stream));
             ctx->dep_check_pending = true;
@@ -774,6 +799,7 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
         }
         ctx->noalloc_scratch = static_cast<unsigned char*>(p);
         if (const char* e = std::getenv("RT_JULIA_HOT_STEPS")) ctx->julia_hot_steps = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+        if (const char* e = std::getenv("RT_PHOTON_ORDER_SORT")) ctx->dep_force_sort = std::atoi(e) != 0;
         if (const char* e = std::getenv("RT_JULIA_GROUP_TILES")) ctx->julia_group_tiles = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
     }
     (void)hipMemset(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long));
@@ -791,7 +817,7 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->h_arena) (void)hipHostFree(ctx->h_arena);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
-    for (Buffer* b : {&ctx->scene_arena, &ctx->bvh_nodes, &ctx->atlas, &ctx->out8, &ctx->acc, &ctx->samples, &ctx->stack, &ctx->out_staging, &ctx->kat_a, &ctx->kat_b, &ctx->kat_c, &ctx->kat_d, &ctx->sched,
+    for (Buffer* b : {&ctx->scene_arena, &ctx->bvh_nodes, &ctx->atlas, &ctx->out8, &ctx->acc, &ctx->samples, &ctx->stack, &ctx->out_staging, &ctx->kat_a, &ctx->kat_b, &ctx->kat_c, &ctx->kat_d, &ctx->sched, &ctx->dep_count, &ctx->dep_seg_first, &ctx->dep_runs, &ctx->dep_seg_vals,
                       &ctx->dep_keys, &ctx->dep_vals, &ctx->dep_sorted_keys, &ctx->dep_sorted_index, &ctx->dep_long_runs, &ctx->dep_temp, &ctx->live_dirs}) {
         if (b->ptr) (void)hipFree(b->ptr);
     }

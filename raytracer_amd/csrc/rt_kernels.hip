@@ -2836,6 +2836,7 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                         job.dep_keys[slot_index] = (deposit_texel << (job.dep_root_bits + job.dep_seq_bits)) |
                                                    (root_id << job.dep_seq_bits) | root_deposits;
                         job.dep_vals[slot_index] = make_float4(deposit_rad[0], deposit_rad[1], deposit_rad[2], deposit_rad[3]);
+                        if (job.dep_count != nullptr) job.dep_slot[slot_index] = atomicAdd(job.dep_count + deposit_texel, 1u);
                         add_now = false;
                     } else {
                         atomicAdd(job.dep_words + 1, 1ull);   // buffer full: this deposit is added out of order (host grows the buffer)

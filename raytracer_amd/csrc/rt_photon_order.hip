@@ -5,14 +5,22 @@
 // order of the recursion (refraction subtree, then reflection; src/photonmap.cpp:118-144).  Float
 // addition does not commute in the last bit, so float atomics give textures that agree to rounding
 // only.  Here the deposits recorded by photon_kernel — key = (texel, root id, number within the root),
-// exactly that order — are sorted (rocPRIM radix sort over the significant key bits, payload = record
-// index) and every texel's run is added up front to back, starting from the zero the texture is
-// created with: the same additions in the same order as the reference, hence the same floats.
+// exactly that order — are brought into key order per texel and every texel's run is added up front to
+// back, starting from the zero the texture is created with: the same additions in the same order as
+// the reference, hence the same floats.
 //
-// Runs are short almost everywhere (one thread per run); a texel in a caustic's focus can receive
-// thousands of deposits, and such a run (>= kDepositLongRun) is summed by a wave: 64 records staged in
-// LDS per round, four lanes adding one channel each, so the chain costs an LDS read and an add per
-// record instead of a dependent global load.
+// photon_order_bucket (the default): no global sort.  What matters is the order WITHIN a texel, and runs
+// are short (C5: 0.37 M deposits in 16 k texels, the longest run 201; 9_caustic: 2.1 M in 66 k, longest
+// 288): photon_kernel counts the deposits per texel while it records them; every non-empty texel gets
+// a segment, the records are scattered into their segments, and one wave per texel ranks its run in
+// LDS (rank = number of smaller keys) and adds it up in rank order, four lanes adding one channel each.
+// Three launches instead of the thirty-odd
+// of a 52-bit device-wide sort [MI355X, C5: 0.25 -> see DESIGN.md 4.6].  Runs beyond the LDS tile are
+// ranked against global memory (slow, correct for any length).
+//
+// photon_order_reduce (the fallback, for atlases of 2^31 texels or more): rocPRIM radix/merge sort over
+// the significant key bits with the record index as payload, one thread per short run, a wave per long
+// one (>= kDepositLongRun: 64 records staged in LDS per round).
 #include <hip/hip_runtime.h>
 
 #include <cstring>   // rocprim's texture_cache_iterator.hpp uses memset without including it
@@ -99,7 +107,141 @@ __global__ __launch_bounds__(64) void sum_long_runs_kernel(const unsigned long l
     }
 }
 
+// ---- photon_order_bucket ------------------------------------------------------------------------------------------------
+constexpr unsigned kRunTile = 320;       // records of a run that a wave ranks and sums in LDS at a time (7.5 KB: twenty-one waves per CU;
+                                         // the kernel is a chain of dependent loads per run, so waves in flight are what it needs)
+
+// One thread per texel: every non-empty texel gets a segment of the scattered arrays and an entry {texel, first, length} in
+// the run list.  Segments and entries are handed out block by block with one atomic (low word: records, high word: runs) —
+// where a texel's segment lies does not matter.
+__global__ __launch_bounds__(256) void place_runs_kernel(unsigned* __restrict__ count, unsigned n_texels, unsigned* __restrict__ seg_first,
+                                                         uint4* __restrict__ runs, unsigned long long* __restrict__ cursor) {
+    __shared__ unsigned long long wave_total[4];
+    __shared__ unsigned long long block_base;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    const unsigned c = t < n_texels ? count[t] : 0u;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long v = static_cast<unsigned long long>(c) | (c != 0u ? 1ull << 32 : 0ull);   // inclusive scan of (records, runs) over the block
+    for (unsigned off = 1; off < 64; off <<= 1) {
+        const unsigned long long up = __shfl_up(v, off);
+        if (lane >= off) v += up;
+    }
+    if (lane == 63) wave_total[wave] = v;
+    __syncthreads();
+    unsigned long long before = 0;
+    for (unsigned w = 0; w < wave; w++) before += wave_total[w];
+    if (threadIdx.x == 255) {
+        const unsigned long long total = before + v;
+        block_base = total != 0ull ? atomicAdd(cursor, total) : 0ull;
+    }
+    __syncthreads();
+    if (c != 0u) {
+        const unsigned long long mine = block_base + before + v - (static_cast<unsigned long long>(c) | (1ull << 32));   // exclusive
+        const unsigned first = static_cast<unsigned>(mine), slot = static_cast<unsigned>(mine >> 32);
+        seg_first[t] = first;
+        runs[slot] = make_uint4(t, first, c, 0u);
+        count[t] = 0u;                                  // for the next pass
+    }
+}
+
+// Records into their texels' segments: record i goes to the place photon_kernel's count gave it (slot[i] = the texel's
+// count when it arrived), so no atomic is needed here.
+__global__ __launch_bounds__(256) void scatter_records_kernel(const unsigned long long* __restrict__ keys, unsigned capacity, unsigned shift,
+                                                              unsigned long long n_texels, const unsigned* __restrict__ slot, const unsigned* __restrict__ seg_first,
+                                                              const float4* __restrict__ vals, unsigned long long* __restrict__ seg_keys, float4* __restrict__ seg_vals) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= capacity) return;
+    const unsigned long long key = keys[i];
+    const unsigned long long texel = texel_of(key, shift);
+    if (texel >= n_texels) return;
+    const unsigned at = seg_first[texel] + slot[i];
+    seg_keys[at] = key;
+    seg_vals[at] = vals[i];
+}
+
+__device__ __forceinline__ bool key_before(unsigned long long a, unsigned ia, unsigned long long b, unsigned ib) { return a < b || (a == b && ia < ib); }
+
+// acc + v[0] + v[1] + ... in that order, channel `c`: eight LDS reads in flight, then their additions (a read per addition
+// would wait out the LDS latency n times over)
+__device__ __forceinline__ float add_in_order(float acc, const float4* v, unsigned n, unsigned c) {
+    unsigned j = 0;
+    for (; j + 8 <= n; j += 8) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[k] = reinterpret_cast<const float*>(&v[j + k])[c];
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc += t[k];
+    }
+    for (; j < n; j++) acc += reinterpret_cast<const float*>(&v[j])[c];
+    return acc;
+}
+
+// One wave per run (grid-stride over the run list): rank, gather in rank order, add.
+__global__ __launch_bounds__(64) void sum_runs_kernel(const uint4* __restrict__ runs, const unsigned long long* __restrict__ cursor,
+                                                      const unsigned long long* __restrict__ seg_keys, const float4* __restrict__ seg_vals,
+                                                      float4* __restrict__ atlas, unsigned* __restrict__ order) {
+    __shared__ unsigned long long lkeys[kRunTile];
+    __shared__ float4 lvals[kRunTile];
+    const unsigned lane = threadIdx.x;
+    const unsigned n_runs = static_cast<unsigned>(*cursor >> 32);
+    for (unsigned r = blockIdx.x; r < n_runs; r += gridDim.x) {
+        const uint4 run = runs[r];
+        const unsigned texel = run.x, first = run.y, len = run.z;
+        float acc = lane < 4 ? reinterpret_cast<const float*>(atlas + texel)[lane] : 0.0f;   // zero, or the surplus of a pass that outgrew the record buffer
+        if (len <= kRunTile) {
+            for (unsigned e = lane; e < len; e += 64) lkeys[e] = seg_keys[first + e];
+            __syncthreads();
+            for (unsigned e = lane; e < len; e += 64) {
+                const unsigned long long k = lkeys[e];
+                unsigned rank = 0;
+                for (unsigned j = 0; j < len; j++) rank += key_before(lkeys[j], j, k, e) ? 1u : 0u;
+                lvals[rank] = seg_vals[first + e];
+            }
+            __syncthreads();
+            if (lane < 4) acc = add_in_order(acc, lvals, len, lane);
+            __syncthreads();
+        } else {
+            // a run beyond the tile: ranks against global memory (the run's own segment of `order` takes the record indices
+            // in key order), then the sum tile by tile
+            for (unsigned e = lane; e < len; e += 64) {
+                const unsigned long long k = seg_keys[first + e];
+                unsigned rank = 0;
+                for (unsigned j = 0; j < len; j++) rank += key_before(seg_keys[first + j], j, k, e) ? 1u : 0u;
+                order[first + rank] = first + e;
+            }
+            __threadfence_block();
+            __syncthreads();
+            for (unsigned base = 0; base < len; base += kRunTile) {
+                const unsigned n = len - base < kRunTile ? len - base : kRunTile;
+                for (unsigned e = lane; e < n; e += 64) lvals[e] = seg_vals[order[first + base + e]];
+                __syncthreads();
+                if (lane < 4) acc = add_in_order(acc, lvals, n, lane);
+                __syncthreads();
+            }
+        }
+        if (lane < 4) reinterpret_cast<float*>(atlas + texel)[lane] = acc;
+    }
+}
+
 }  // namespace
+
+// The ordered sums without a global sort (see the head of this file).  count: [n_texels], the deposits per texel as
+// photon_kernel counted them while it recorded (DevPhotonJob::dep_count; left at zero again); slot: [capacity], a
+// record's number within its texel (DevPhotonJob::dep_slot); seg_first: [n_texels]; runs, seg_keys, seg_vals, order:
+// [capacity]; cursor: one word, zero.
+hipError_t photon_order_bucket(const unsigned long long* keys, const float4* vals, const unsigned* slot, unsigned capacity, unsigned texel_shift, unsigned n_texels,
+                               float4* atlas, unsigned* count, unsigned* seg_first, uint4* runs, unsigned long long* seg_keys, float4* seg_vals,
+                               unsigned* order, unsigned long long* cursor, hipStream_t stream) {
+    hipError_t e;
+    hipLaunchKernelGGL(place_runs_kernel, dim3((n_texels + 255) / 256), dim3(256), 0, stream, count, n_texels, seg_first, runs, cursor);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(scatter_records_kernel, dim3((capacity + 255) / 256), dim3(256), 0, stream, keys, capacity, texel_shift,
+                       static_cast<unsigned long long>(n_texels), slot, seg_first, vals, seg_keys, seg_vals);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    const unsigned blocks = capacity < 16384u ? (capacity > 0u ? capacity : 1u) : 16384u;
+    hipLaunchKernelGGL(sum_runs_kernel, dim3(blocks), dim3(64), 0, stream, runs, cursor, seg_keys, seg_vals, atlas, order);
+    return hipGetLastError();
+}
 
 // Bytes of temporary storage the sort needs for `capacity` records
 hipError_t photon_order_temp_bytes(unsigned capacity, unsigned key_bits, size_t* bytes) {

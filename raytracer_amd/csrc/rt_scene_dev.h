@@ -233,6 +233,8 @@ struct DevPhotonJob {
     unsigned long long* dep_keys;   // [dep_capacity], preset to ~0 (sorts last)
     float4* dep_vals;               // [dep_capacity]
     unsigned long long* dep_words;  // [0] next free record, [1] deposits that found the buffer full
+    uint32_t* dep_count;            // [texels of the atlas] deposits recorded per texel (photon_order_bucket), or NULL
+    uint32_t* dep_slot;             // [dep_capacity] a record's number within its texel (the count it found)
     uint32_t dep_capacity;
     uint32_t dep_seq_bits;          // key = texel << (dep_root_bits + dep_seq_bits) | root << dep_seq_bits | seq
     uint32_t dep_root_bits;
