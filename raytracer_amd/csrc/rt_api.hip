@@ -140,6 +140,7 @@ struct rt_ctx {
     Buffer dep_keys, dep_vals, dep_sorted_keys, dep_sorted_index, dep_long_runs, dep_temp;
     Buffer dep_count, dep_seg_first, dep_runs, dep_seg_vals;   // photon_order_bucket: deposits per texel (zero between passes), first record of a texel's segment, run list
     bool dep_bucket = false;                     // the pass in preparation sums by buckets (atlases below 2^31 texels)
+    bool dense_with_bvh = false;                 // RT_DENSE_BVH=1 in the environment (developer A/B): the dense variant for BVH scenes too
     bool dep_force_sort = false;                 // RT_PHOTON_ORDER_SORT=1 in the environment: the device-wide sort instead (developer A/B, tests)
     Buffer live_dirs;                            // RT_OPT_CULL_PHOTON_ROOTS: the directions of the photon pass that may meet a specular object
     uint32_t dep_capacity = 0;         // records; 0 = choose from the number of roots
@@ -252,6 +253,15 @@ void free_scene(rt_ctx* ctx) {
     ctx->has_scene = false;
 }
 
+// The dense variant of trace_kernel (four workgroups per CU) for a scene with a BVH: what is left of the CU's LDS beside
+// the parked state and the frame tops is two stack entries per lane; shading tables and BVH records are read through the
+// vector cache.
+void dense_bvh_layout(DevScene& sc) {
+    sc.shade_blob_in_lds = 0;
+    sc.bvh_records_in_lds = 0;
+    sc.bvh_lds_stack_entries = 2;
+}
+
 // tiles / samples of one render call
 void make_job(const rt_ctx* ctx, const rt_bands* bands, DevJob* job) {
     const DevScene& sc = ctx->dev;
@@ -331,6 +341,7 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     // the samples to occupy them several times over (measured: C3, 33 M samples, gains 8 %; C5, 90 k samples, loses 7 %)
     const bool dense = !julia && ctx->dense_blocks_per_cu[stats] >= 4 && job.n_samples >= kDenseMinSamples;
     if (dense) dev.frame_slots_in_lds = 1;
+    if (dense && dev.bvh_nodes != nullptr) dense_bvh_layout(dev);
     const size_t lds = julia ? 0 : dynamic_lds_bytes(dev);
     const uint64_t block_lanes = julia ? kJuliaPoolContexts : 256;   // ray trees in flight per workgroup
     {
@@ -800,6 +811,7 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
         ctx->noalloc_scratch = static_cast<unsigned char*>(p);
         if (const char* e = std::getenv("RT_JULIA_HOT_STEPS")) ctx->julia_hot_steps = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
         if (const char* e = std::getenv("RT_PHOTON_ORDER_SORT")) ctx->dep_force_sort = std::atoi(e) != 0;
+        if (const char* e = std::getenv("RT_DENSE_BVH")) ctx->dense_with_bvh = std::atoi(e) != 0;
         if (const char* e = std::getenv("RT_JULIA_GROUP_TILES")) ctx->julia_group_tiles = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
     }
     (void)hipMemset(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long));
@@ -1311,9 +1323,10 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* d) {
         RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->trace_blocks_per_cu[0], trace_kernel<false, false>, 256, lds_t));
         RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->trace_blocks_per_cu[1], trace_kernel<true, false>, 256, lds_t));
         ctx->dense_blocks_per_cu[0] = ctx->dense_blocks_per_cu[1] = 0;
-        if (sc.n_julias == 0 && sc.bvh_nodes == nullptr) {
+        if (sc.n_julias == 0 && (sc.bvh_nodes == nullptr || ctx->dense_with_bvh)) {
             DevScene one_slot = sc;
             one_slot.frame_slots_in_lds = 1;
+            if (sc.bvh_nodes != nullptr) dense_bvh_layout(one_slot);
             const size_t lds_d = dynamic_lds_bytes(one_slot);
             RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->dense_blocks_per_cu[0], trace_kernel<false, true>, 256, lds_d));
             RT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->dense_blocks_per_cu[1], trace_kernel<true, true>, 256, lds_d));

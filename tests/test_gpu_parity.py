@@ -439,6 +439,29 @@ def test_photon_atlas_vs_oracle(hip_ctx):
             assert oracle_lib.image_diff(capi.quantize(img), capi.quantize(ref))["frac_gt1"] == 0.0
 
 
+@pytest.mark.parametrize("size, force_sort", [(6, False), (20, False), (150, False), (20, True), (150, True)])
+def test_photon_order_with_long_runs_and_on_both_paths(size, force_sort, monkeypatch):
+    """rt_photon_order.hip sums a texel's deposits in key order: one wave per run in LDS (runs up to 320 records: all of
+    C5's), against global memory beyond that.  Coarse photon textures make the runs long — 6 x 6 texels take all of the
+    scene's 0.1 M deposits: runs of thousands — and exercise that path; RT_PHOTON_ORDER_SORT=1 selects the device-wide
+    sort that atlases of 2^31 texels would use.  Textures: the oracle's, bit for bit, on every path."""
+    if force_sort:
+        monkeypatch.setenv("RT_PHOTON_ORDER_SORT", "1")
+    ctx = capi.Context(0)        # (the environment is read by rt_create)
+    sc = capi.Scene(scene_path("examples3/103_caustic_steps200.xml"), 0.5)
+    sc.desc.photon_texture_size = size
+    ph = oracle_lib.Photons(sc)
+    assert ph.stats.photon_deposits > 10000
+    ctx.upload(sc)
+    for _ in range(2):           # twice: the per-texel counts must be back at zero after a pass
+        ctx.photon_generate()
+        for o in range(sc.desc.n_objects):
+            a = ctx.photon_download(o)
+            b = ph.texture(o)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (size, o)
+    ctx.close()
+
+
 @pytest.mark.parametrize("source", ["examples3/103_caustic_steps200.xml", 1, 9, 13, 21, 25, 33, 5, 29])
 def test_photon_roots_that_can_leave_nothing_are_not_traced(hip_ctx, source, tmp_path):
     """The reference deposits a light ray only after a specular bounce (src/photonmap.cpp:79-83), so a root whose ray

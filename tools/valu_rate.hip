@@ -73,6 +73,12 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, float seed) {
             if (KIND == 31) asm volatile("v_cmp_gt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m) : "vcc");
             if (KIND == 32) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
             if (KIND == 33) asm volatile("v_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %2, %0" : "+v"(a[i]) : "v"(m), "s"(seed));   // alternating VGPR / SGPR
+            // ---- latency: ONE dependent chain per lane (what a lone wave pays per instruction of a chain)
+            if (KIND == 42) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[0]) : "v"(pc));
+            if (KIND == 43) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[0]) : "v"(pm));
+            if (KIND == 44) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[0]) : "v"(c));
+            if (KIND == 45) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[0]) : "v"(dm), "v"(dc));
+            if (KIND == 46) { if ((i & 1) == 0) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[0]) : "v"(pc)); else asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[1]) : "v"(pc)); }   // two chains
             // ---- ordering experiments: the same mix of "slow" (SGPR operand / compare / max) and "fast" instructions,
             // grouped (4 slow then 4 fast) or alternating, every instruction on its own chain
             if (KIND == 34) { if ((i & 7) < 4) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i]) : "s"(seed)); else asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m)); }
@@ -158,6 +164,11 @@ int main() {
     run<31>("v_cmp + v_cndmask", d_out, n_cus, 1);
     run<32>("v_xor_b32", d_out, n_cus, 1);
     run<33>("v_mul vgpr, v_mul sgpr", d_out, n_cus, 1);
+    run<42>("one chain of v_pk_add_f32", d_out, n_cus, 1);
+    run<43>("one chain of v_pk_mul_f32", d_out, n_cus, 1);
+    run<44>("one chain of v_add_f32", d_out, n_cus, 1);
+    run<45>("one chain of v_fma_f64", d_out, n_cus, 1);
+    run<46>("two chains of v_pk_add_f32", d_out, n_cus, 1);
     run<34>("4 sgpr-mul, 4 mul grouped", d_out, n_cus, 1);
     run<35>("sgpr-mul, mul alternating", d_out, n_cus, 1);
     run<36>("4 max, 4 mul grouped", d_out, n_cus, 1);
