@@ -252,7 +252,7 @@ constexpr uint32_t kDepositLongRun = 32;    // deposits into one texel from whic
 #define RT_JULIA_WAVES 12
 #endif
 #ifndef RT_JULIA_MARCHERS
-#define RT_JULIA_MARCHERS 10
+#define RT_JULIA_MARCHERS 9       // [MI355X, round 3] 10 + 2: 26.7 ms, eighths of the bands 14.2-17.0; 9 + 3: 26.1, 13.0-16.2; 8 + 4: 26.7, 11.8-15.1 but 90.7 against 87 ms at four times the size
 #endif
 #ifndef RT_JULIA_DUAL
 #define RT_JULIA_DUAL 0             // 1: marcher lanes hold two jobs and one estimator state (rt_kernels.hip: julia_marcher_dual)
