@@ -399,10 +399,32 @@ def units_line(args, capi, driver, world, rank, local_rank, dev):
                             "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
                             "note": "algorithmic flops of the 160 units / GPU-busy time of the render calls (upload + photon pass + trace per unit, "
                                     "event pairs on the render stream); per-kernel figures are on the c5 line"}
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """stdout carries ONE JSON line: libraries that write to file descriptor 1 themselves (RCCL prints a version banner
+    there when a process group starts) get stderr instead; emit() writes the line to the real stdout."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    data = (json.dumps(line) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, data)
 
 
 def progress(msg):
@@ -421,6 +443,7 @@ def main():
     ap.add_argument("--bvh-min", type=int, default=None, help="developer: RT_OPT_BVH_MIN_TRIANGLES before the upload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    claim_stdout()
 
     import torch
     import torch.distributed as dist
@@ -593,7 +616,7 @@ def main():
                 if ref is not None:
                     extra["c5_cpu_reference"] = ref
             line["extra"] = extra
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -29,6 +29,18 @@ import torch.distributed as dist
 from . import capi
 
 BAND_ROWS = 8
+# HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (4 by default) and two streams on one queue run
+# one after the other.  render_units keeps three units in flight on three streams beside the caller's own, a download
+# stream and RCCL's: with four queues two of its lanes can land on the same one (measured on the 160-unit C5 file inside
+# bench.py's `extra`: 1 510 units/s instead of 1 790).  Eight are asked for when this module is imported before the HIP
+# runtime starts and the process has not asked for more; a host that must keep four sets RT_KEEP_HW_QUEUES=1.
+HW_QUEUES = 8
+if os.environ.get("RT_KEEP_HW_QUEUES", "0") in ("", "0") and not torch.cuda.is_initialized():
+    try:
+        if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < HW_QUEUES:
+            os.environ["GPU_MAX_HW_QUEUES"] = str(HW_QUEUES)
+    except ValueError:
+        pass
 # <caustic steps> from which a still's photon pass is split over the ranks: 1000 steps = 500 000 directions
 # per light (0.6 ms on one MI355X at C5's size, against some 50 us for the all-reduce of the textures)
 SPLIT_PHOTON_MIN_STEPS = 1000.0
@@ -75,13 +87,15 @@ class HipRenderer:
         return total * 1e-3
 
     def lanes(self):
-        """[(renderer, stream)] that render_units alternates its units over: this renderer and a twin (a second context on
-        the same GPU; RT_DRIVER_LANES - 1 of them) on side streams, so that the photon pass of one unit runs beside the
-        trace kernel of the one before — either leaves half of the GPU idle on frames of C5's size.
-        RT_DRIVER_OVERLAP=0: this renderer alone on the current stream."""
+        """[(renderer, stream)] that render_units alternates its units over: this renderer and its twins (further contexts on
+        the same GPU; RT_DRIVER_LANES - 1 of them, two by default) on side streams, so that the photon pass of one unit runs
+        beside the trace kernels of the ones before — a C5 frame is a chain of dependent queries that leaves more than half
+        of the GPU idle on its own.  Measured on the 160-unit C5 file [MI355X]: 1 390 units/s with two lanes, 1 790 with
+        three, 1 530-1 570 with four, 1 440-1 680 with five (the VALU is busy 59 % of a lone C5 render: a third render in
+        flight has nothing left to fill; tools/lanes_sweep.sh).  RT_DRIVER_OVERLAP=0: this renderer alone on the current stream."""
         if os.environ.get("RT_DRIVER_OVERLAP", "1") in ("", "0"):
             return [(self, None)]
-        n = max(2, int(os.environ.get("RT_DRIVER_LANES", "2")))
+        n = max(2, int(os.environ.get("RT_DRIVER_LANES", "3")))
         if len(getattr(self, "_twins", [])) != n - 1:
             self.close_twins()
             self._twins = [HipRenderer(self.device.index) for _ in range(n - 1)]

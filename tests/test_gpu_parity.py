@@ -341,8 +341,8 @@ def test_rccl_gathers_of_the_pipelined_driver(monkeypatch):
         dist.destroy_process_group()
 
 
-def test_units_alternating_over_two_contexts_give_the_same_frames(monkeypatch):
-    """driver.render_units alternates its units over two contexts on two streams (the photon pass of one unit beside the
+def test_units_alternating_over_several_contexts_give_the_same_frames(monkeypatch):
+    """driver.render_units alternates its units over three contexts (two with RT_DRIVER_LANES=2) on as many streams (the photon pass of one unit beside the
     trace kernel of the one before) and confirms a unit's photon pass a round late.  The frames must be those of one
     context on one stream and of the lock-step loop — also when every photon pass is found too small for its record
     buffer at first and the unit is rendered again (a fresh pair of contexts with a tiny buffer)."""
@@ -351,25 +351,28 @@ def test_units_alternating_over_two_contexts_give_the_same_frames(monkeypatch):
     monkeypatch.setenv("RT_DRIVER_SEQUENTIAL", "1")
     want = [driver.render_frames(driver.HipRenderer(0), f)[0] for f in files]
     monkeypatch.setenv("RT_DRIVER_SEQUENTIAL", "0")
-    for overlap in ("0", "1"):
+    for overlap, n_lanes in (("0", "3"), ("1", "2"), ("1", "3"), ("1", "5")):
         monkeypatch.setenv("RT_DRIVER_OVERLAP", overlap)
+        monkeypatch.setenv("RT_DRIVER_LANES", n_lanes)
         r = driver.HipRenderer(0)
         for f, frames in zip(files, want):
             got = driver.render_frames(r, f)[0]
             assert len(got) == len(frames)
             for a, b in zip(got, frames):
-                assert np.array_equal(a, b), overlap
+                assert np.array_equal(a, b), (overlap, n_lanes)
+        r.close()
     monkeypatch.setenv("RT_DRIVER_OVERLAP", "1")
+    monkeypatch.delenv("RT_DRIVER_LANES")
     r = driver.HipRenderer(0)
     lanes = r.lanes()
-    assert len(lanes) == 2 and lanes[0][0] is r
+    assert len(lanes) == 3 and lanes[0][0] is r
     reruns = []
     for lane, _stream in lanes:
         lane.ctx.set_option(capi.RT_OPT_PHOTON_RECORDS, 4096)       # far too few: the first pass of each context overflows
         ok = lane.photon_pass_ok
         lane.photon_pass_ok = (lambda ok=ok: reruns.append(ok()) or reruns[-1])
     got = driver.render_frames(r, files[0])[0]
-    assert reruns.count(False) >= 2
+    assert reruns.count(False) >= len(lanes)
     for a, b in zip(got, want[0]):
         assert np.array_equal(a, b)
     # options set on the renderer's context reach the twin that renders the alternate units, whenever they were set
