@@ -2659,6 +2659,9 @@ __global__ __launch_bounds__(256) void photon_cull_kernel(const DevScene sc, con
 // a stack of pending rays.  Deposits are RECORDED with their position in the reference's sequential pass
 // (root id, number within the root) for rt_photon_order.hip to sum per texel in that order — or, with
 // RT_OPT_PHOTON_ORDER = 0, added to the atlas with float atomics (texels equal to rounding only).
+//
+// The newest pending ray of a lane lives in LDS ([field][lane], like trace_kernel's frame top), older ones in the lane's
+// stack column in HBM: a pop costs an LDS read, not a memory round trip in the middle of the lane's chain of queries.
 template <bool HAS_JULIA, bool STATS>
 __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(const DevScene sc, const DevPhotonJob job) {
     Counters n;
@@ -2695,6 +2698,9 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
     L.sp = 0;
     float rad[4] = {0, 0, 0, 0};
     unsigned depth = 0;
+    __shared__ float top_store[kFrameFields * 256];
+    float* const top = top_store + threadIdx.x;      // the lane's newest pending ray: field c at top[c * 256]
+    bool has_top = false;                // ... is there; L.sp counts the older ones in HBM
     bool need = true;
     // the ids to hand out: every root of the launch, or (RT_OPT_CULL_PHOTON_ROOTS) the hues of the directions that
     // photon_cull_kernel kept — their number is known on the device only, so the split of the id space is made here
@@ -2710,6 +2716,8 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
     unsigned root_deposits = 0;          // together the position of a deposit in the reference's sequential pass
     bool cullable = false;               // counters build: this root lies outside the cull box (traced all the same; must not meet a specular object)
     unsigned long long dep_next = 0, dep_end = 0;   // records this wave has reserved (wave-uniform)
+    unsigned long long slot_owed = ~0ull;           // record whose number within its texel (slot_value) is still to be stored
+    unsigned slot_value = 0;
     for (;;) {
         // refill idle lanes with new roots
         while (__any(need)) {
@@ -2813,13 +2821,18 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                     const bool refr_ok = kr < 1.0f && refraction_ray(L.qd, L.best.point, L.best.normal, m.refr_re, m.dispersion, cosv, L.wavelength, ro, rd);
                     reflection_ray(L.qd, L.best.point, L.best.normal, cosv, mo, md);
                     if (refr_ok) {
-                        // reflection (always cast, src/photonmap.cpp:141-144) waits on the stack
-                        const unsigned f = L.sp;
-                        stack.at(f, 0) = mo.x; stack.at(f, 1) = mo.y; stack.at(f, 2) = mo.z;
-                        stack.at(f, 3) = md.x; stack.at(f, 4) = md.y; stack.at(f, 5) = md.z;
-                        for (int c = 0; c < 4; c++) stack.at(f, 6 + c) = rad[c] * kr;
-                        stack.at(f, 10) = __uint_as_float(depth + 1);
-                        L.sp = f + 1;
+                        // reflection (always cast, src/photonmap.cpp:141-144) waits on the stack: in LDS, the ray that was there in HBM
+                        if (has_top) {
+                            const unsigned f = L.sp;
+#pragma unroll
+                            for (int c = 0; c < kFrameFields; c++) stack.at(f, c) = top[c * 256];
+                            L.sp = f + 1;
+                        }
+                        top[0 * 256] = mo.x; top[1 * 256] = mo.y; top[2 * 256] = mo.z;
+                        top[3 * 256] = md.x; top[4 * 256] = md.y; top[5 * 256] = md.z;
+                        for (int c = 0; c < 4; c++) top[(6 + c) * 256] = rad[c] * kr;
+                        top[10 * 256] = __uint_as_float(depth + 1);
+                        has_top = true;
                         for (int c = 0; c < 4; c++) rad[c] = rad[c] * (1 - kr);
                         begin_query(L, ro, rd, kInfinite, Q_PHOTON);
                     } else {
@@ -2831,7 +2844,14 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                 }
             }
             if (pop) {
-                if (L.sp > 0) {
+                if (has_top) {
+                    const V3 o = v3(top[0 * 256], top[1 * 256], top[2 * 256]);
+                    const V3 d = v3(top[3 * 256], top[4 * 256], top[5 * 256]);
+                    for (int c = 0; c < 4; c++) rad[c] = top[(6 + c) * 256];
+                    depth = __float_as_uint(top[10 * 256]);
+                    has_top = false;
+                    begin_query(L, o, d, kInfinite, Q_PHOTON);
+                } else if (L.sp > 0) {
                     const unsigned f = L.sp - 1;
                     const V3 o = v3(stack.at(f, 0), stack.at(f, 1), stack.at(f, 2));
                     const V3 d = v3(stack.at(f, 3), stack.at(f, 4), stack.at(f, 5));
@@ -2869,7 +2889,12 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                         job.dep_keys[slot_index] = (deposit_texel << (job.dep_root_bits + job.dep_seq_bits)) |
                                                    (root_id << job.dep_seq_bits) | root_deposits;
                         job.dep_vals[slot_index] = make_float4(deposit_rad[0], deposit_rad[1], deposit_rad[2], deposit_rad[3]);
-                        if (job.dep_count != nullptr) job.dep_slot[slot_index] = atomicAdd(job.dep_count + deposit_texel, 1u);
+                        if (job.dep_count != nullptr) {
+                            // the count the atomic returns is stored at the lane's next deposit (or at the end): nothing waits for the round trip
+                            if (slot_owed != ~0ull) job.dep_slot[slot_owed] = slot_value;
+                            slot_value = atomicAdd(job.dep_count + deposit_texel, 1u);
+                            slot_owed = slot_index;
+                        }
                         add_now = false;
                     } else {
                         atomicAdd(job.dep_words + 1, 1ull);   // buffer full: this deposit is added out of order (host grows the buffer)
@@ -2886,6 +2911,7 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
             }
         }
     }
+    if (slot_owed != ~0ull) job.dep_slot[slot_owed] = slot_value;
     flush_counters<STATS>(n, job.counters);
 }
 
