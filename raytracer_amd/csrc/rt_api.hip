@@ -145,13 +145,15 @@ struct rt_ctx {
     Buffer live_dirs;                            // RT_OPT_CULL_PHOTON_ROOTS: the directions of the photon pass that may meet a specular object
     uint32_t dep_capacity = 0;         // records; 0 = choose from the number of roots
     size_t dep_temp_bytes = 0;
-    unsigned long long* d_dep_words = nullptr;   // [0] records reserved, [1] deposits that found the buffer full, [2] long runs, [3] deposits beyond a root's key field, [4] live directions (photon_cull_kernel), [5] photon_order_bucket's cursor
+    unsigned long long* d_dep_words = nullptr;   // [0] records reserved, [1] deposits that found the buffer full, [2] long runs, [3] deposits beyond a root's key field, [4] live directions (photon_cull_kernel), [5] photon_order_bucket's cursor, [6] records or runs it found outside the record buffer (internal error), [8..10] developer build RT_GUARD: first index violation (site, index, limit)
     unsigned long long* h_dep_words = nullptr;   // pinned copy, written by the stream after every ordered pass
     hipEvent_t ev_dep = nullptr;
     bool dep_check_pending = false;
     bool dep_last_pass_ordered = false;
     bool dep_last_pass_overflowed = false;   // sticky until the next pass is enqueued
     bool dep_key_too_narrow = false;         // a root made more deposits than the order key has bits for
+    bool dep_misplaced = false;              // the bucket kernels met a segment outside the record buffer (never seen with sound counts: an internal error)
+    bool poison_allocations = false;         // RT_POISON_ALLOC=1 when the context was created
     // per-call scratch, grown on demand and kept
     Buffer samples, stack, out_staging, out8, acc, kat_a, kat_b, kat_c, kat_d, sched;
     uint32_t julia_group_tiles = RT_JULIA_GROUP_TILES;   // DevJob::group_tiles; RT_JULIA_GROUP_TILES in the environment overrides it (developer sweeps)
@@ -194,6 +196,16 @@ int fail(rt_ctx* ctx, int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(ctx, RT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));  \
     } while (0)
 
+// RT_HIP_SYNC_EACH=1 (developer aid): wait after every kernel of a photon pass and name the one that failed, instead of
+// hearing of a fault at the next synchronisation with no kernel attached to it.
+int step_check(rt_ctx* ctx, hipStream_t stream, const char* what) {
+    static const bool sync_each = [] { const char* e = std::getenv("RT_HIP_SYNC_EACH"); return e != nullptr && e[0] != '0' && e[0] != 0; }();
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && sync_each) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    return RT_OK;
+}
+
 int grow(rt_ctx* ctx, Buffer& b, size_t bytes) {
     if (b.bytes >= bytes && b.ptr) return RT_OK;
     if (b.ptr) RT_HIP_TRY(ctx, hipFree(b.ptr));
@@ -201,6 +213,9 @@ int grow(rt_ctx* ctx, Buffer& b, size_t bytes) {
     b.bytes = 0;
     RT_HIP_TRY(ctx, hipMalloc(&b.ptr, bytes));
     b.bytes = bytes;
+    // RT_POISON_ALLOC=1 (tests): a new buffer starts full of 0xA5 bytes, so that code which counts on fresh memory being
+    // zero fails every time instead of when the allocator happens to return a used block
+    if (ctx->poison_allocations) RT_HIP_TRY(ctx, hipMemset(b.ptr, 0xA5, bytes));
     return RT_OK;
 }
 
@@ -499,6 +514,7 @@ bool deposit_overflow_seen(rt_ctx* ctx) {
     ctx->dep_check_pending = false;
     ctx->dep_last_pass_overflowed = ctx->h_dep_words[1] != 0 || ctx->h_dep_words[3] != 0;
     ctx->dep_key_too_narrow = ctx->h_dep_words[3] != 0;
+    ctx->dep_misplaced = ctx->h_dep_words[6] != 0;
     if (ctx->h_dep_words[1] == 0) return false;
     const unsigned long long wanted = ctx->h_dep_words[0] + ctx->h_dep_words[0] / 4;
     ctx->dep_capacity = static_cast<uint32_t>(std::min<unsigned long long>((wanted + 65535ull) & ~65535ull, 1ull << 31));
@@ -524,10 +540,13 @@ int deposit_buffers(rt_ctx* ctx, unsigned long long all_roots, unsigned key_bits
         if ((rc = grow(ctx, ctx->dep_seg_first, n_texels * sizeof(unsigned))) != RT_OK) return rc;
         if ((rc = grow(ctx, ctx->dep_runs, n * sizeof(uint4))) != RT_OK) return rc;
         if ((rc = grow(ctx, ctx->dep_seg_vals, n * sizeof(float4))) != RT_OK) return rc;
-        const void* const before = ctx->dep_count.ptr;
+        const size_t before = ctx->dep_count.bytes;
         if ((rc = grow(ctx, ctx->dep_count, n_texels * sizeof(unsigned))) != RT_OK) return rc;
-        // zero once: every pass leaves the counts at zero again (scatter_records_kernel)
-        if (ctx->dep_count.ptr != before) RT_HIP_TRY(ctx, hipMemsetAsync(ctx->dep_count.ptr, 0, ctx->dep_count.bytes, stream));
+        // zero once per allocation: every pass leaves the counts at zero again (place_runs_kernel).  The SIZE tells a new
+        // allocation, not the address: the allocator may hand the freed block's address out again for the larger one, whose
+        // tail then holds whatever was there (found by tools/fuzz_parity.py on a fresh context: counts of 10^9, records
+        // scattered far outside their buffer, a memory fault in scatter_records_kernel)
+        if (ctx->dep_count.bytes != before) RT_HIP_TRY(ctx, hipMemsetAsync(ctx->dep_count.ptr, 0, ctx->dep_count.bytes, stream));
         return RT_OK;
     }
     if ((rc = grow(ctx, ctx->dep_long_runs, (n / kDepositLongRun + 1) * sizeof(unsigned))) != RT_OK) return rc;
@@ -583,7 +602,7 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
         job.queue_head = ctx->d_queue;
         job.counters = ctx->d_counters;
         RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 2 * sizeof(unsigned long long), stream));
-        RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_dep_words, 0, 8 * sizeof(unsigned long long), stream));   // every control word of the pass at once
+        RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_dep_words, 0, 16 * sizeof(unsigned long long), stream));   // every control word of the pass at once
         // reference deposit order: record, sort, sum (rt_photon_order.hip) when the key fits 64 bits
         const unsigned long long n_texels = static_cast<unsigned long long>(ctx->n_slots) * ctx->dev.photon_size * ctx->dev.photon_size;
         // a root deposits at most once per leaf of its tree, 2^(max_bounces+1) in theory; when the key has no room for
@@ -595,6 +614,7 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
         const bool ordered = ctx->photon_order && seq_bits >= std::min<unsigned>(ctx->dev.max_bounces + 2, 10);
         ctx->dep_last_pass_ordered = ordered;
         ctx->dep_last_pass_overflowed = false;
+        ctx->dep_misplaced = false;
         if (ordered) {
             if ((rc = deposit_buffers(ctx, all_roots, key_bits, n_texels, stream)) != RT_OK) return rc;
             job.dep_keys = static_cast<unsigned long long*>(ctx->dep_keys.ptr);
@@ -607,6 +627,12 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
             job.dep_root_bits = root_bits;
             RT_HIP_TRY(ctx, hipMemsetAsync(ctx->dep_keys.ptr, 0xFF, static_cast<size_t>(ctx->dep_capacity) * sizeof(unsigned long long), stream));
         }
+#ifdef RT_GUARD
+        job.guard_words = ctx->d_dep_words + 8;       // the first violation: site, index, limit
+        job.guard_texels = n_texels;
+        job.guard_dirs = static_cast<uint64_t>(job.n_point_lights) * job.n_phi * job.n_theta;
+        job.guard_stack_frames = ctx->dev.max_bounces + 1;
+#endif
         // roots that can leave nothing are dropped before the pass (DevScene::photon_cull_*; not for a slice of the pass,
         // and not under counters: that launch traces every root and checks the claim)
         job.static_sixteenths = RT_STATIC_SHARE_PHOTON;
@@ -616,7 +642,7 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
             if ((rc = grow(ctx, ctx->live_dirs, n_dirs * sizeof(uint32_t))) != RT_OK) return rc;
             hipLaunchKernelGGL(photon_cull_kernel, dim3(static_cast<unsigned>((n_dirs + 255) / 256)), dim3(256), 0, stream, ctx->dev, job,
                                static_cast<unsigned>(n_dirs), static_cast<uint32_t*>(ctx->live_dirs.ptr), ctx->d_dep_words + 4);
-            RT_HIP_TRY(ctx, hipGetLastError());
+            if ((rc = step_check(ctx, stream, "photon_cull_kernel")) != RT_OK) return rc;
             job.live_dirs = static_cast<const uint32_t*>(ctx->live_dirs.ptr);
             job.live_count = ctx->d_dep_words + 4;
         }
@@ -627,7 +653,7 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
             if (stats) hipLaunchKernelGGL((photon_kernel<false, true>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
             else hipLaunchKernelGGL((photon_kernel<false, false>), dim3(blocks), dim3(256), lds, stream, ctx->dev, job);
         }
-        RT_HIP_TRY(ctx, hipGetLastError());
+        if ((rc = step_check(ctx, stream, "photon_kernel")) != RT_OK) return rc;
         if (ordered) {
             if (ctx->dep_bucket)
                 RT_HIP_TRY(ctx, photon_order_bucket(job.dep_keys, job.dep_vals, job.dep_slot, ctx->dep_capacity, root_bits + seq_bits, static_cast<unsigned>(n_texels), ctx->dev.photon_atlas,
@@ -638,7 +664,8 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
                 RT_HIP_TRY(ctx, photon_order_reduce(job.dep_keys, job.dep_vals, ctx->dep_capacity, key_bits, root_bits + seq_bits, n_texels, ctx->dev.photon_atlas,
                                                     static_cast<unsigned long long*>(ctx->dep_sorted_keys.ptr), static_cast<unsigned*>(ctx->dep_sorted_index.ptr),
                                                     static_cast<unsigned*>(ctx->dep_long_runs.ptr), ctx->d_dep_words, ctx->dep_temp.ptr, ctx->dep_temp_bytes, stream));
-            RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_dep_words, ctx->d_dep_words, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            if ((rc = step_check(ctx, stream, "the ordered sum of the photon deposits")) != RT_OK) return rc;
+            RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_dep_words, ctx->d_dep_words, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
             RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_dep, stream));
             ctx->dep_check_pending = true;
         }
@@ -783,6 +810,10 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
     if (device_id < 0 || device_id >= count) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "device %d out of range (0..%d)", device_id, count - 1);
     rt_ctx* ctx = new rt_ctx;
     ctx->device = device_id;
+    {
+        const char* e = std::getenv("RT_POISON_ALLOC");
+        ctx->poison_allocations = e != nullptr && e[0] != '0' && e[0] != 0;
+    }
     hipDeviceProp_t prop;
     if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&prop, device_id) != hipSuccess) {
         delete ctx;
@@ -791,8 +822,8 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
     ctx->n_cus = prop.multiProcessorCount;
     if (hipMalloc(reinterpret_cast<void**>(&ctx->d_queue), 256) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), C_COUNT * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&ctx->d_dep_words), 8 * sizeof(unsigned long long)) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&ctx->h_dep_words), 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&ctx->d_dep_words), 16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&ctx->h_dep_words), 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), 2 * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&ctx->ev_dep) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) {
@@ -1365,6 +1396,7 @@ int rt_photon_ordered(rt_ctx* ctx, int* ordered_out) {
     if (ctx->dep_check_pending) RT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_dep));
     const bool overflowed = deposit_overflow_seen(ctx) || ctx->dep_last_pass_overflowed;
     ctx->dep_last_pass_overflowed = overflowed;
+    if (ctx->dep_misplaced) return fail(ctx, RT_ERR_HIP, "photon pass: the ordered sum met records outside its buffer (internal error: the textures of this pass are incomplete)");
     *ordered_out = overflowed ? 0 : 1;
     return RT_OK;
 }
@@ -1381,6 +1413,13 @@ int rt_photon_generate(rt_ctx* ctx, rt_stats* stats) {
     int rc = rt_photon_generate_device(ctx, nullptr);
     if (rc != RT_OK) return rc;
     RT_HIP_TRY(ctx, hipStreamSynchronize(nullptr));
+#ifdef RT_GUARD
+    {
+        unsigned long long w[16] = {};
+        RT_HIP_TRY(ctx, hipMemcpy(w, ctx->d_dep_words, sizeof w, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "RT_GUARD: records %llu, live dirs %llu, cursor %llx; first violation: site %llu index %llu limit %llu\n", w[0], w[4], w[5], w[8], w[9], w[10]);
+    }
+#endif
     if (deposit_overflow_seen(ctx)) {
         // the record buffer was too small for this scene: it has been resized from what the pass reported;
         // run the pass again so that the caller gets the reference's order
@@ -1388,6 +1427,7 @@ int rt_photon_generate(rt_ctx* ctx, rt_stats* stats) {
         RT_HIP_TRY(ctx, hipStreamSynchronize(nullptr));
         if (deposit_overflow_seen(ctx)) return fail(ctx, RT_ERR_LIMIT, "photon deposits do not fit the record buffer (%llu wanted)", ctx->h_dep_words[0]);
     }
+    if (ctx->dep_misplaced) return fail(ctx, RT_ERR_HIP, "photon pass: the ordered sum met records outside its buffer (internal error: the textures of this pass are incomplete)");
     return read_stats(ctx, stats);
 }
 

@@ -2651,7 +2651,11 @@ __global__ __launch_bounds__(256) void photon_cull_kernel(const DevScene sc, con
     unsigned long long base = 0;
     if (static_cast<int>(lane) == leader) base = atomicAdd(live_count, static_cast<unsigned long long>(__popcll(mask)));
     base = __shfl(base, leader);
+#ifdef RT_GUARD
+    if (live && RT_GUARD_OK(job.guard_words, 8, base + __popcll(mask & ((1ull << lane) - 1ull)), job.guard_dirs)) live_dirs[base + __popcll(mask & ((1ull << lane) - 1ull))] = d;
+#else
     if (live) live_dirs[base + __popcll(mask & ((1ull << lane) - 1ull))] = d;
+#endif
 }
 
 // ---- photon pass (src/photonmap.cpp:20-146) ---------------------------------------------------------
@@ -2733,7 +2737,12 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                         // ids count the hues of the LIVE directions (photon_cull_kernel); the root keeps its number in the full pass
                         const unsigned i32 = static_cast<unsigned>(id);
                         hue = i32 % job.hues;
+#ifdef RT_GUARD
+                        const unsigned dir_id = RT_GUARD_OK(job.guard_words, 3, i32 / job.hues, *job.live_count) ? job.live_dirs[i32 / job.hues] : 0u;
+                        (void)RT_GUARD_OK(job.guard_words, 31, dir_id, job.guard_dirs);
+#else
                         const unsigned dir_id = job.live_dirs[i32 / job.hues];
+#endif
                         root_id = static_cast<unsigned long long>(dir_id) * job.hues + hue;
                         ti = dir_id % job.n_theta;
                         const unsigned q = dir_id / job.n_theta;
@@ -2759,6 +2768,11 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                         li = static_cast<unsigned>(q / job.n_phi);
                     }
                     root_deposits = 0;
+#ifdef RT_GUARD
+                    if (!RT_GUARD_OK(job.guard_words, 71, ti, job.n_theta)) ti = 0;
+                    if (!RT_GUARD_OK(job.guard_words, 72, pi, job.n_phi)) pi = 0;
+                    if (!RT_GUARD_OK(job.guard_words, 73, li, job.n_point_lights)) li = 0;
+#endif
                     const DevLight& light = T.lights[job.point_lights[li]];
                     const V3 origin = v3(light.position[0], light.position[1], light.position[2]);
                     const V3 dir = photon_root_direction(job, ti, pi);
@@ -2801,6 +2815,9 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
             }
             finish_best_triangle(T, L);
             bool pop = true;
+#ifdef RT_GUARD
+            if (L.found && !RT_GUARD_OK(job.guard_words, 4, L.best_obj, sc.n_objects)) L.found = 0u;
+#endif
             if (L.found) {
                 const DevMaterial& m = T.materials[T.object_material[L.best_obj]];
                 if (m.refr_norm <= 0.0f) {
@@ -2822,7 +2839,7 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                     reflection_ray(L.qd, L.best.point, L.best.normal, cosv, mo, md);
                     if (refr_ok) {
                         // reflection (always cast, src/photonmap.cpp:141-144) waits on the stack: in LDS, the ray that was there in HBM
-                        if (has_top) {
+                        if (has_top && RT_GUARD_OK(job.guard_words, 1, L.sp, job.guard_stack_frames)) {
                             const unsigned f = L.sp;
 #pragma unroll
                             for (int c = 0; c < kFrameFields; c++) stack.at(f, c) = top[c * 256];
@@ -2851,7 +2868,7 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                     depth = __float_as_uint(top[10 * 256]);
                     has_top = false;
                     begin_query(L, o, d, kInfinite, Q_PHOTON);
-                } else if (L.sp > 0) {
+                } else if (L.sp > 0 && RT_GUARD_OK(job.guard_words, 2, L.sp - 1, job.guard_stack_frames)) {
                     const unsigned f = L.sp - 1;
                     const V3 o = v3(stack.at(f, 0), stack.at(f, 1), stack.at(f, 2));
                     const V3 d = v3(stack.at(f, 3), stack.at(f, 4), stack.at(f, 5));
@@ -2866,6 +2883,9 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
             }
         }
         // Object::addPhoton (src/objects.cpp:244-256), with the wave converged again
+#ifdef RT_GUARD
+        if (deposit && !RT_GUARD_OK(job.guard_words, 5, deposit_texel, job.guard_texels)) deposit = false;
+#endif
         const unsigned long long dep_mask = __ballot(deposit);
         if (dep_mask != 0) {
             bool add_now = deposit;
@@ -2891,7 +2911,7 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                         job.dep_vals[slot_index] = make_float4(deposit_rad[0], deposit_rad[1], deposit_rad[2], deposit_rad[3]);
                         if (job.dep_count != nullptr) {
                             // the count the atomic returns is stored at the lane's next deposit (or at the end): nothing waits for the round trip
-                            if (slot_owed != ~0ull) job.dep_slot[slot_owed] = slot_value;
+                            if (slot_owed != ~0ull && RT_GUARD_OK(job.guard_words, 6, slot_owed, job.dep_capacity)) job.dep_slot[slot_owed] = slot_value;
                             slot_value = atomicAdd(job.dep_count + deposit_texel, 1u);
                             slot_owed = slot_index;
                         }
@@ -2911,7 +2931,7 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
             }
         }
     }
-    if (slot_owed != ~0ull) job.dep_slot[slot_owed] = slot_value;
+    if (slot_owed != ~0ull && RT_GUARD_OK(job.guard_words, 61, slot_owed, job.dep_capacity)) job.dep_slot[slot_owed] = slot_value;
     flush_counters<STATS>(n, job.counters);
 }
 

@@ -22,6 +22,8 @@
 // the significant key bits with the record index as payload, one thread per short run, a wave per long
 // one (>= kDepositLongRun: 64 records staged in LDS per round).
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 
 #include <cstring>   // rocprim's texture_cache_iterator.hpp uses memset without including it
 
@@ -108,6 +110,14 @@ __global__ __launch_bounds__(64) void sum_long_runs_kernel(const unsigned long l
 }
 
 // ---- photon_order_bucket ------------------------------------------------------------------------------------------------
+#ifdef RT_GUARD
+// developer build (tools/guard_build.sh): index checks; the first violation goes to cursor[3..5] = control words 8..10 (site, index, limit) and the access is skipped
+#define RT_PO_OK(cursor, site, index, limit) \
+    (static_cast<unsigned long long>(index) < static_cast<unsigned long long>(limit) ? true : \
+     (atomicCAS(const_cast<unsigned long long*>(cursor) + 3, 0ull, static_cast<unsigned long long>(site)) == 0ull ? (const_cast<unsigned long long*>(cursor)[4] = static_cast<unsigned long long>(index), const_cast<unsigned long long*>(cursor)[5] = static_cast<unsigned long long>(limit), false) : false))
+#else
+#define RT_PO_OK(cursor, site, index, limit) true
+#endif
 constexpr unsigned kRunTile = 320;       // records of a run that a wave ranks and sums in LDS at a time (7.5 KB: twenty-one waves per CU;
                                          // the kernel is a chain of dependent loads per run, so waves in flight are what it needs)
 
@@ -115,7 +125,7 @@ constexpr unsigned kRunTile = 320;       // records of a run that a wave ranks a
 // the run list.  Segments and entries are handed out block by block with one atomic (low word: records, high word: runs) —
 // where a texel's segment lies does not matter.
 __global__ __launch_bounds__(256) void place_runs_kernel(unsigned* __restrict__ count, unsigned n_texels, unsigned* __restrict__ seg_first,
-                                                         uint4* __restrict__ runs, unsigned long long* __restrict__ cursor) {
+                                                         uint4* __restrict__ runs, unsigned long long* __restrict__ cursor, unsigned capacity) {
     __shared__ unsigned long long wave_total[4];
     __shared__ unsigned long long block_base;
     const unsigned t = blockIdx.x * 256u + threadIdx.x;
@@ -139,7 +149,9 @@ __global__ __launch_bounds__(256) void place_runs_kernel(unsigned* __restrict__ 
         const unsigned long long mine = block_base + before + v - (static_cast<unsigned long long>(c) | (1ull << 32));   // exclusive
         const unsigned first = static_cast<unsigned>(mine), slot = static_cast<unsigned>(mine >> 32);
         seg_first[t] = first;
-        runs[slot] = make_uint4(t, first, c, 0u);
+        (void)RT_PO_OK(cursor, 102, static_cast<unsigned long long>(first) + c - 1ull, capacity);
+        if (RT_PO_OK(cursor, 101, slot, capacity) && slot < capacity) runs[slot] = make_uint4(t, first, c, 0u);   // (slot < capacity with sound counts: a run has a record)
+        else atomicAdd(cursor + 1, 1ull);
         count[t] = 0u;                                  // for the next pass
     }
 }
@@ -148,13 +160,19 @@ __global__ __launch_bounds__(256) void place_runs_kernel(unsigned* __restrict__ 
 // count when it arrived), so no atomic is needed here.
 __global__ __launch_bounds__(256) void scatter_records_kernel(const unsigned long long* __restrict__ keys, unsigned capacity, unsigned shift,
                                                               unsigned long long n_texels, const unsigned* __restrict__ slot, const unsigned* __restrict__ seg_first,
-                                                              const float4* __restrict__ vals, unsigned long long* __restrict__ seg_keys, float4* __restrict__ seg_vals) {
+                                                              const float4* __restrict__ vals, unsigned long long* __restrict__ seg_keys, float4* __restrict__ seg_vals,
+                                                              const unsigned long long* __restrict__ cursor) {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= capacity) return;
     const unsigned long long key = keys[i];
     const unsigned long long texel = texel_of(key, shift);
     if (texel >= n_texels) return;
     const unsigned at = seg_first[texel] + slot[i];
+    if (!RT_PO_OK(cursor, 111, at, capacity)) return;
+    if (at >= capacity) {       // never with sound counts (the segments partition the records): reported, not written
+        atomicAdd(const_cast<unsigned long long*>(cursor) + 1, 1ull);
+        return;
+    }
     seg_keys[at] = key;
     seg_vals[at] = vals[i];
 }
@@ -183,17 +201,26 @@ __device__ __forceinline__ float add_in_order(float acc, const float4* v, unsign
 // go to LDS at their rank), two memory round trips per run instead of four.
 __global__ __launch_bounds__(64) void sum_runs_kernel(const uint4* __restrict__ runs, unsigned capacity, const unsigned long long* __restrict__ cursor,
                                                       const unsigned long long* __restrict__ seg_keys, const float4* __restrict__ seg_vals,
-                                                      float4* __restrict__ atlas, unsigned* __restrict__ order) {
+                                                      float4* __restrict__ atlas, unsigned* __restrict__ order, unsigned n_texels) {
+    const unsigned guard_texels = n_texels;
     __shared__ unsigned long long lkeys[kRunTile];
     __shared__ float4 lvals[kRunTile];
     constexpr unsigned kPerLane = kRunTile / 64u;
     static_assert(kRunTile % 64u == 0u, "a tile is a whole number of wave-wide rows");
     const unsigned lane = threadIdx.x;
     uint4 run = blockIdx.x < capacity ? runs[blockIdx.x] : uint4{0u, 0u, 0u, 0u};    // (entries from the run count up hold whatever the last pass left)
-    const unsigned n_runs = static_cast<unsigned>(*cursor >> 32);
+    const unsigned counted = static_cast<unsigned>(*cursor >> 32);
+    const unsigned n_runs = counted < capacity ? counted : capacity;
     for (unsigned r = blockIdx.x; r < n_runs; r += gridDim.x) {
         if (r != blockIdx.x) run = runs[r];
         const unsigned texel = run.x, first = run.y, len = run.z;
+#ifdef RT_GUARD
+        if (!RT_PO_OK(cursor, 121, texel, guard_texels) || !RT_PO_OK(cursor, 122, static_cast<unsigned long long>(first) + len - 1ull, capacity) || len == 0u) continue;
+#endif
+        if (texel >= guard_texels || static_cast<unsigned long long>(first) + len > capacity) {     // (as in scatter_records_kernel)
+            if (lane == 0) atomicAdd(const_cast<unsigned long long*>(cursor) + 1, 1ull);
+            continue;
+        }
         float acc = lane < 4 ? reinterpret_cast<const float*>(atlas + texel)[lane] : 0.0f;   // zero, or the surplus of a pass that outgrew the record buffer
         if (len <= kRunTile) {
             unsigned long long k[kPerLane];
@@ -218,7 +245,7 @@ __global__ __launch_bounds__(64) void sum_runs_kernel(const uint4* __restrict__ 
                 if (e < len) {
                     unsigned rank = 0;
                     for (unsigned j = 0; j < len; j++) rank += key_before(lkeys[j], j, k[i], e) ? 1u : 0u;
-                    lvals[rank] = v[i];
+                    if (RT_PO_OK(cursor, 123, rank, len)) lvals[rank] = v[i];
                 }
             }
             __syncthreads();
@@ -231,13 +258,16 @@ __global__ __launch_bounds__(64) void sum_runs_kernel(const uint4* __restrict__ 
                 const unsigned long long k = seg_keys[first + e];
                 unsigned rank = 0;
                 for (unsigned j = 0; j < len; j++) rank += key_before(seg_keys[first + j], j, k, e) ? 1u : 0u;
-                order[first + rank] = first + e;
+                if (RT_PO_OK(cursor, 124, rank, len)) order[first + rank] = first + e;
             }
             __threadfence_block();
             __syncthreads();
             for (unsigned base = 0; base < len; base += kRunTile) {
                 const unsigned n = len - base < kRunTile ? len - base : kRunTile;
-                for (unsigned e = lane; e < n; e += 64) lvals[e] = seg_vals[order[first + base + e]];
+                for (unsigned e = lane; e < n; e += 64) {
+                    const unsigned from = order[first + base + e];
+                    lvals[e] = RT_PO_OK(cursor, 125, from, capacity) ? seg_vals[from] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+                }
                 __syncthreads();
                 if (lane < 4) acc = add_in_order(acc, lvals, n, lane);
                 __syncthreads();
@@ -256,15 +286,23 @@ __global__ __launch_bounds__(64) void sum_runs_kernel(const uint4* __restrict__ 
 hipError_t photon_order_bucket(const unsigned long long* keys, const float4* vals, const unsigned* slot, unsigned capacity, unsigned texel_shift, unsigned n_texels,
                                float4* atlas, unsigned* count, unsigned* seg_first, uint4* runs, unsigned long long* seg_keys, float4* seg_vals,
                                unsigned* order, unsigned long long* cursor, hipStream_t stream) {
+    // RT_HIP_SYNC_EACH=1 (developer aid, as in rt_api.hip): wait after every kernel and say on stderr which one failed
+    static const bool sync_each = [] { const char* v = std::getenv("RT_HIP_SYNC_EACH"); return v != nullptr && v[0] != '0' && v[0] != 0; }();
+    auto after = [&](const char* what) {
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess && sync_each) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess && sync_each) std::fprintf(stderr, "photon_order_bucket: %s: %s\n", what, hipGetErrorString(e));
+        return e;
+    };
     hipError_t e;
-    hipLaunchKernelGGL(place_runs_kernel, dim3((n_texels + 255) / 256), dim3(256), 0, stream, count, n_texels, seg_first, runs, cursor);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(place_runs_kernel, dim3((n_texels + 255) / 256), dim3(256), 0, stream, count, n_texels, seg_first, runs, cursor, capacity);
+    if ((e = after("place_runs_kernel")) != hipSuccess) return e;
     hipLaunchKernelGGL(scatter_records_kernel, dim3((capacity + 255) / 256), dim3(256), 0, stream, keys, capacity, texel_shift,
-                       static_cast<unsigned long long>(n_texels), slot, seg_first, vals, seg_keys, seg_vals);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+                       static_cast<unsigned long long>(n_texels), slot, seg_first, vals, seg_keys, seg_vals, cursor);
+    if ((e = after("scatter_records_kernel")) != hipSuccess) return e;
     const unsigned blocks = capacity < 16384u ? (capacity > 0u ? capacity : 1u) : 16384u;
-    hipLaunchKernelGGL(sum_runs_kernel, dim3(blocks), dim3(64), 0, stream, runs, capacity, cursor, seg_keys, seg_vals, atlas, order);
-    return hipGetLastError();
+    hipLaunchKernelGGL(sum_runs_kernel, dim3(blocks), dim3(64), 0, stream, runs, capacity, cursor, seg_keys, seg_vals, atlas, order, n_texels);
+    return after("sum_runs_kernel");
 }
 
 // Bytes of temporary storage the sort needs for `capacity` records

@@ -243,7 +243,20 @@ struct DevPhotonJob {
     // may meet a specular object, DevScene::photon_cull_*) instead of over all of them.  NULL: every root.
     const uint32_t* live_dirs;              // direction = (light * n_phi + phi) * n_theta + theta
     const unsigned long long* live_count;   // how many (device memory: known only after photon_cull_kernel ran)
+#ifdef RT_GUARD
+    // developer build (tools/guard_build.sh): every index of the pass is checked against these; the first violation is
+    // reported in guard_words[0] (site) and [1] (index) and the access is skipped
+    unsigned long long* guard_words;
+    uint64_t guard_texels, guard_dirs, guard_stack_frames;
+#endif
 };
+#ifdef RT_GUARD
+#define RT_GUARD_OK(words, site, index, limit) \
+    (static_cast<unsigned long long>(index) < static_cast<unsigned long long>(limit) ? true : \
+     (atomicCAS((words), 0ull, static_cast<unsigned long long>(site)) == 0ull ? ((words)[1] = static_cast<unsigned long long>(index), (words)[2] = static_cast<unsigned long long>(limit), false) : false))
+#else
+#define RT_GUARD_OK(words, site, index, limit) true
+#endif
 constexpr uint32_t kDepositChunk = 32;      // records a wave reserves per atomic
 constexpr uint32_t kDepositLongRun = 32;    // deposits into one texel from which a wave sums them (rt_photon_order.hip)
 

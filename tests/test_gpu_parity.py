@@ -498,6 +498,35 @@ def test_photon_roots_that_can_leave_nothing_are_not_traced(hip_ctx, source, tmp
         hip_ctx.set_option(capi.RT_OPT_CULL_PHOTON_ROOTS, 1)
 
 
+def test_photon_pass_on_a_fresh_context_does_not_count_on_zeroed_memory(monkeypatch, tmp_path):
+    """A context whose buffers grow from scene to scene (tools/fuzz_parity.py's situation; the shared context of this
+    file has long reached its largest sizes): photon textures of three scenes with ever larger atlases, then of fuzz
+    seeds whose pass once scattered its records outside their buffer — the per-texel counts of the ordered sum were
+    zeroed only when the allocation's ADDRESS changed, and the allocator may hand a freed block's address out again.
+    RT_POISON_ALLOC=1 fills every new buffer with 0xA5 so that such a dependence shows every time."""
+    import mesh_scene
+    monkeypatch.setenv("RT_POISON_ALLOC", "1")
+    ctx = capi.Context(0)
+    try:
+        sources = [13, 1001, 1005, 1009, 1, "examples3/103_caustic_steps200.xml"]
+        for source in sources:
+            if isinstance(source, int):
+                sc = capi.Scene(mesh_scene.write_random_scene(tmp_path, source), 0.0)
+            else:
+                sc = capi.Scene(scene_path(source), 0.5)
+            ph = oracle_lib.Photons(sc)
+            ctx.upload(sc)
+            st = ctx.photon_generate()
+            assert ctx.photon_ordered()
+            for o in range(sc.desc.n_objects):
+                assert np.array_equal(ctx.photon_download(o).view(np.uint32), ph.texture(o).view(np.uint32)), (source, o)
+            img, _ = ctx.render()
+            ref, _ = oracle_lib.render(sc, ph, threads=8)
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), source
+    finally:
+        ctx.close()
+
+
 def test_photon_record_buffer_grows_when_a_scene_outgrows_it(hip_ctx):
     """A record buffer far too small for the scene's deposits: rt_photon_generate must notice, resize from
     what the pass reported, run again and return the reference's textures; the asynchronous entry point

@@ -25,6 +25,8 @@ def main():
         ctx.set_option(capi.RT_OPT_BVH_MIN_TRIANGLES, int(sys.argv[3]))
     bad = []
     for seed in range(first, last):
+        if os.environ.get("FUZZ_TRACE"):       # (a run that faults the GPU loses its files: say on stdout where it is)
+            print("begin seed", seed, flush=True)
         sc = capi.Scene(mesh_scene.write_random_scene(tmp, seed), 0.0)
         if len(sys.argv) > 4:       # larger pictures: more tiles than waves, so the dynamic part of the work distribution runs
             if sc.desc.n_julias > 0:
