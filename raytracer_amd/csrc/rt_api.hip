@@ -215,7 +215,11 @@ int grow(rt_ctx* ctx, Buffer& b, size_t bytes) {
     b.bytes = bytes;
     // RT_POISON_ALLOC=1 (tests): a new buffer starts full of 0xA5 bytes, so that code which counts on fresh memory being
     // zero fails every time instead of when the allocator happens to return a used block
-    if (ctx->poison_allocations) RT_HIP_TRY(ctx, hipMemset(b.ptr, 0xA5, bytes));
+    // (hipMemset may return before the fill has run, and the caller's stream need not wait for the default stream: wait here)
+    if (ctx->poison_allocations) {
+        RT_HIP_TRY(ctx, hipMemset(b.ptr, 0xA5, bytes));
+        RT_HIP_TRY(ctx, hipDeviceSynchronize());
+    }
     return RT_OK;
 }
 
