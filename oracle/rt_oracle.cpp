@@ -243,6 +243,9 @@ V3 julia_normal(const rt_julia& j, Quat pos, float diff, Counters& n) {
 // ones bound the latency of a frame whatever the machine's throughput.
 thread_local uint64_t t_sample_longest_march = 0;      // longest single march of the sample being rendered
 thread_local std::vector<uint32_t>* t_march_log = nullptr;   // oracle_pixel_marches: steps of every march, bit 31 = shadow ray
+// Diagnostic (oracle_pixel_rays): every castRay of the pixel being rendered, 12 floats a piece:
+// recursion, wavelength, origin (3), direction (3), found, object, distance, cosine.
+thread_local std::vector<float>* t_ray_log = nullptr;
 std::atomic<uint64_t> g_march_hist[16];        // marches of 2^(k-1) < steps <= 2^k
 std::atomic<uint64_t> g_march_hist_steps[16];  // ... their steps
 std::atomic<uint64_t> g_march_longest_iterations{0};   // estimator iterations of the march with the most of them
@@ -453,6 +456,11 @@ struct Tracer {
             hit = h;
             hit_object = k;
             hit_cos = cos_rn;
+        }
+        if (t_ray_log != nullptr) {
+            const float rec[12] = {static_cast<float>(recursion), wavelength, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z,
+                                   found ? 1.0f : 0.0f, static_cast<float>(hit_object), found ? hit.distance : 0.0f, hit_cos};
+            t_ray_log->insert(t_ray_log->end(), rec, rec + 12);
         }
         if (!found) return col4(sc.background);
 
@@ -932,6 +940,20 @@ uint32_t oracle_pixel_marches(const rt_scene_desc* sc, uint32_t x, uint32_t y, u
 }
 
 void oracle_set_deposit_counts(uint32_t* per_texel) { g_deposit_counts = per_texel; }
+
+// Diagnostic: every castRay of pixel (x, y), all of its samples in order, 12 floats a piece (recursion, wavelength, origin,
+// direction, found, object, distance, cosine).  Returns how many there were (at most `cap` are written).
+uint32_t oracle_pixel_rays(const rt_scene_desc* sc, const oracle_photons* photons, uint32_t x, uint32_t y, float* out, uint32_t cap) {
+    std::vector<float> log;
+    t_ray_log = &log;
+    Tracer tr{*sc, photons ? &photons->maps : nullptr, {}};
+    const CameraFrame frame = camera_frame(sc->camera);
+    (void)render_pixel(tr, frame, x, y);
+    t_ray_log = nullptr;
+    const uint32_t n = static_cast<uint32_t>(log.size() / 12);
+    for (uint32_t i = 0; i < n && i < cap; i++) std::memcpy(out + 12 * i, log.data() + 12 * i, 12 * sizeof(float));
+    return n;
+}
 
 // Diagnostic: {steps, iterations, Julia queries} of the sample with the most march steps and of the one with the most
 // estimator iterations since the last call.  Not part of any parity check.

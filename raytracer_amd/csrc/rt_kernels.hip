@@ -455,9 +455,32 @@ RT_DEV void query_objects(const DevScene& sc, Lane& L, bool in_phase, const BvhS
 
 // Julia hits are judged after the uniform loop; the rule below is the order-independent form of the
 // reference's sequential one (nearest wins, equal distances go to the later scene object).
-RT_DEV void accept_julia_hit(Lane& L, const HitRec& h, const DevJulia& j, const DevMaterial& m) {
+//
+// With one exception, which is not order-independent in the reference either.  Sphere::intersect does not compare its
+// distance with the maximum: it carries the maximum into object space — the LENGTH of o - w2o(o_w + d_w * max) — and
+// compares the ray parameter with that (src/objects.cpp:33-38).  Far from the origin o_w + d_w * max lands on a grid
+// point (at 5 000 units the grid is 0.0005 wide), the length is that noisy, and a sphere tested AFTER a set that has
+// just been hit nearer is accepted all the same, or rejected at the very same distance (tools/fuzz_parity.py, seed 5477:
+// two pixels).  So when the winner so far is a sphere that comes after this set in the scene, the reference's own question
+// is put: does that sphere still report a hit with the set's distance as its maximum?  (The loop tested it with a
+// maximum that did not know of the set's hit.)
+RT_DEV const DevSphere* sphere_of_object(const DevScene& sc, unsigned obj) {
+    for (unsigned r = 0; r < sc.n_runs; r++) {
+        const DevRun& run = sc.runs[r];
+        if (obj >= run.first_object && obj - run.first_object < run.count) return run.kind == RUN_SPHERES ? sc.spheres + run.first_prim + (obj - run.first_object) : nullptr;
+    }
+    return nullptr;
+}
+RT_DEV void accept_julia_hit(const DevScene& sc, Lane& L, const HitRec& h, const DevJulia& j, const DevMaterial& m) {
     if (L.qkind != Q_SHADOW) {
-        const bool nearer = h.dist < L.qmax || (h.dist == L.qmax && (!L.found || j.object > L.best_obj));
+        bool nearer = h.dist < L.qmax || (h.dist == L.qmax && (!L.found || j.object > L.best_obj));
+        if (L.found != 0u && L.best_obj > j.object && L.best_tri == kNoTriangle) {
+            // (an unseen back face of the set changes nothing in the reference's loop: accept_hit below drops it either way)
+            if (const DevSphere* sphere = sphere_of_object(sc, L.best_obj)) {
+                HitRec again;
+                nearer = !sphere_intersect(sphere, L.qo, L.qd, h.dist, again);
+            }
+        }
         if (!nearer) return;
     }
     accept_hit(L, h, j.object, m.transmittance, m.refr_norm);
@@ -2368,7 +2391,7 @@ RT_DEV void julia_shader(const DevScene& sc, const ShadeTables& T, const DevJob&
             if (jstatus == JOB_HIT) {
                 // Julia::intersect ignores max_distance until this final check (src/objects.cpp:236)
                 const float limit = L.qkind == Q_SHADOW ? L.qmax : kInfinite;
-                if (!(jhit.dist > limit)) accept_julia_hit(L, jhit, j, T.materials[j.material]);
+                if (!(jhit.dist > limit)) accept_julia_hit(sc, L, jhit, j, T.materials[j.material]);
             }
             L.state = S_RESOLVE;
             if (L.qactive) {
@@ -2808,7 +2831,7 @@ __global__ __launch_bounds__(256, RT_PHOTON_WAVES_PER_SIMD) void photon_kernel(c
                     HitRec h;
                     unsigned long long steps = 0, iters = 0;
                     bump<STATS>(n, C_JULIA_QUERIES);
-                    if (julia_intersect_inline<STATS>(j, L.qo, L.qd, kInfinite, h, steps, iters)) accept_julia_hit(L, h, j, T.materials[j.material]);
+                    if (julia_intersect_inline<STATS>(j, L.qo, L.qd, kInfinite, h, steps, iters)) accept_julia_hit(sc, L, h, j, T.materials[j.material]);
                     bump<STATS>(n, C_JULIA_STEPS, steps);
                     bump<STATS>(n, C_JULIA_DE_ITERATIONS, iters);
                 }

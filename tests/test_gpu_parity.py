@@ -931,7 +931,7 @@ def test_degenerate_scenes(hip_ctx, tmp_path, case):
         assert pst.photon_deposits > 32 * 64      # many deposits per texel: the long-run path of rt_photon_order.hip
 
 
-@pytest.mark.parametrize("seed", list(range(32)) + [78])
+@pytest.mark.parametrize("seed", list(range(32)) + [78, 5477])      # 5477: a sphere behind a Julia set, 5 000 units from the origin (accept_julia_hit)
 def test_random_scenes_vs_oracle(hip_ctx, tmp_path, seed):
     """Seeded random scenes over the whole grammar of the path (tests/mesh_scene.py: write_random_scene):
     pictures, photon textures and ray counts bit-exact against the oracle."""
