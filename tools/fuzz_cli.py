@@ -42,6 +42,8 @@ def main():
             text = text.replace("<camera>", tags + "<camera>", 1)
             open(scene, "w").write(text)
         a, b = str(tmp / "ref.png"), str(tmp / "hip.png")
+        if os.environ.get("FUZZ_TRACE"):       # (the reference takes minutes for some animated Julia scenes: say which one is running)
+            print("begin seed", seed, flush=True)
         subprocess.check_call([ref_exe, scene, a], stdout=subprocess.DEVNULL)
         subprocess.check_call([cli, scene, b], stdout=subprocess.DEVNULL)
         n += 1
