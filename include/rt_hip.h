@@ -272,8 +272,9 @@ int rt_fetch_stats(rt_ctx* ctx, rt_stats* out);
  * more than one sample per pixel) and the per-lane ray-tree frame stacks; when the stacks of a full persistent grid
  * do not fit, fewer workgroups are launched (slower, same result).  RT_ERR_LIMIT with a message that names the
  * sizes when the sample buffer, or the stacks of a single workgroup, do not fit.  Counters are not collected
- * (RT_OPT_COLLECT_STATS is ignored).  A frame with Julia sets hands its samples out in plain image order here (the
- * lists by which rt_render_device starts long samples first are an allocation of the context): same picture, slower.  ALL calls on one GPU share that GPU's workspace: two calls that overlap in
+ * (RT_OPT_COLLECT_STATS is ignored).  The lists by which a frame with Julia sets starts its long samples first come off
+ * the workspace's room for the frame stacks (0.2 MB at 960 x 600 x 4 samples); if that leaves no room for one workgroup's
+ * stacks the samples go out in plain image order: same picture, slower.  ALL calls on one GPU share that GPU's workspace: two calls that overlap in
  * time on one GPU (two streams, two contexts, two threads) race.  rt_launch_status applies as for rt_render_device:
  * the watchdog word of the fixed workspace stays set until a context has seen it there, so an abandoned launch is
  * reported even when further launches of either entry point were enqueued before the status was asked for (and,

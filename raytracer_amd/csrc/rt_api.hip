@@ -371,9 +371,29 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     }
     const size_t frame_bytes_per_lane = static_cast<size_t>(ctx->dev.max_bounces + 1) * (julia ? kFrameRecordWordsHost : kFrameFieldsHost) * sizeof(float);
     const size_t samples_bytes = job.samples_per_pixel > 1 ? job.n_pixels * job.samples_per_pixel * sizeof(float4) : 0;
+    // Julia scenes with several samples per pixel: sample-major blocks and the hot lists (DevJob::sched)
+    job.n_tiles = job.tiles_x * job.tiles_y;
+    size_t sched_zero_words = 0, sched_list_words = 0;
+    job.group_tiles = std::max<uint32_t>(1u, ctx->julia_group_tiles);
+    job.n_groups = (job.n_tiles + job.group_tiles - 1) / job.group_tiles;
+    if (julia && job.samples_per_pixel > 1 && ctx->julia_hot_steps != 0u) {
+        const uint64_t n_blocks = static_cast<uint64_t>(job.n_groups) * job.samples_per_pixel;
+        if (n_blocks < 0x7fffffffull) {
+            sched_zero_words = kSchedHeaderWords + job.n_groups + static_cast<size_t>((n_blocks + 31) / 32);
+            sched_list_words = static_cast<size_t>(kSchedLevels) * job.n_groups * (job.samples_per_pixel - 1);
+        }
+    }
+    const size_t sched_bytes = ((sched_zero_words + sched_list_words) * sizeof(uint32_t) + 255) & ~size_t(255);
     Workspace ws;
     if (fixed != nullptr) {
         ws = *fixed;
+        // the lists come off the front of what the fixed workspace has for the frame stacks (C4: 0.2 MB of its 32), unless
+        // that leaves no room for one workgroup's stacks: then the samples go out in plain order, same picture
+        if (sched_bytes > 0 && ws.stack_bytes >= sched_bytes + block_lanes * frame_bytes_per_lane) {
+            ws.sched = reinterpret_cast<uint32_t*>(ws.stack);
+            ws.stack = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ws.stack) + sched_bytes);
+            ws.stack_bytes -= sched_bytes;
+        }
         if (samples_bytes > ws.samples_bytes)
             return fail(ctx, RT_ERR_LIMIT, "rt_render_device_noalloc: the sample buffer of this frame (%zu bytes: %llu pixels x %u samples) exceeds the %zu bytes the fixed workspace has for it",
                         samples_bytes, static_cast<unsigned long long>(job.n_pixels), job.samples_per_pixel, ws.samples_bytes);
@@ -398,21 +418,10 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
         }
     }
     if (job.samples_per_pixel > 1) job.samples = ws.samples;
-    // Julia scenes with several samples per pixel: sample-major blocks and the hot list (DevJob::sched).  The fixed
-    // workspace of rt_render_device_noalloc has no room set aside for it and keeps the plain order: same picture.
-    job.n_tiles = job.tiles_x * job.tiles_y;
-    size_t sched_zero_words = 0, sched_list_words = 0;
-    job.group_tiles = std::max<uint32_t>(1u, ctx->julia_group_tiles);
-    job.n_groups = (job.n_tiles + job.group_tiles - 1) / job.group_tiles;
-    if (julia && fixed == nullptr && job.samples_per_pixel > 1 && ctx->julia_hot_steps != 0u) {
-        const uint64_t n_blocks = static_cast<uint64_t>(job.n_groups) * job.samples_per_pixel;
-        if (n_blocks < 0x7fffffffull) {
-            sched_zero_words = kSchedHeaderWords + job.n_groups + static_cast<size_t>((n_blocks + 31) / 32);
-            sched_list_words = static_cast<size_t>(kSchedLevels) * job.n_groups * (job.samples_per_pixel - 1);
-            rc = grow(ctx, ctx->sched, (sched_zero_words + sched_list_words) * sizeof(uint32_t));
-            if (rc != RT_OK) return rc;
-            ws.sched = static_cast<uint32_t*>(ctx->sched.ptr);
-        }
+    if (fixed == nullptr && sched_bytes > 0) {
+        rc = grow(ctx, ctx->sched, sched_bytes);
+        if (rc != RT_OK) return rc;
+        ws.sched = static_cast<uint32_t*>(ctx->sched.ptr);
     }
     job.sched = ws.sched;
     job.hot_steps = ctx->julia_hot_steps;
