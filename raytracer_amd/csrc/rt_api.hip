@@ -297,6 +297,11 @@ void make_job(const rt_ctx* ctx, const rt_bands* bands, DevJob* job) {
     job->samples_per_pixel = sc.supersampling * sc.supersampling * (sc.dispersion ? 8u : 1u);
     job->n_samples = static_cast<uint64_t>(job->tiles_x) * job->tiles_y * job->samples_per_pixel * 64ull;
     job->dof_seed = ctx->dof_seed;
+    job->fast_decode = (job->n_samples >> 6) <= 0xffffffffull ? 1u : 0u;
+    job->div_samples = make_div(std::max<uint32_t>(1u, job->samples_per_pixel));
+    job->div_tiles_x = make_div(std::max<uint32_t>(1u, job->tiles_x));
+    job->div_band_rows = make_div(std::max<uint32_t>(1u, job->band_rows));
+    job->div_supersampling = make_div(std::max<uint32_t>(1u, sc.supersampling));
 }
 
 // Ids a wave reserves per atomic: at least 16 reservations per wave for balance, whole 8x8 tiles.

@@ -797,6 +797,7 @@ RT_DEV unsigned hash_u32(unsigned x) {
     return x;
 }
 
+RT_DEV bool start_sample_at(const DevScene& sc, const DevJob& job, Lane& L, unsigned x, unsigned y, unsigned yc, unsigned s, unsigned hue, unsigned sub, unsigned sx, unsigned sy);
 // Decodes a sample id and builds its camera ray (src/raytracer.cpp:56-93).  Returns false for the
 // padding lanes of edge tiles.
 RT_DEV bool start_sample(const DevScene& sc, const DevJob& job, unsigned long long id, Lane& L) {
@@ -804,6 +805,20 @@ RT_DEV bool start_sample(const DevScene& sc, const DevJob& job, unsigned long lo
     const unsigned long long q = id >> 6;
     // blocks of 64 ids: tile-major (every sample of a tile, then the next tile), or sample-major under DevJob::sched
     unsigned s, tile;
+    if (job.sched == nullptr && job.fast_decode != 0u) {
+        // the launch's divisors as multiplications (rt_divide.h)
+        tile = divmod_u32(static_cast<unsigned>(q), job.div_samples, s);
+        unsigned tx, by;
+        const unsigned ty = divmod_u32(tile, job.div_tiles_x, tx);
+        const unsigned x = tx * 8 + (p & 7), yc = ty * 8 + (p >> 3);
+        if (x >= sc.width || yc >= job.compact_rows) return false;
+        const unsigned band = divmod_u32(yc, job.div_band_rows, by);
+        const unsigned y = (job.first_band + band * job.band_stride) * job.band_rows + by;
+        const unsigned hue = sc.dispersion ? s & 7u : 0u, sub = sc.dispersion ? s >> 3 : s;
+        unsigned sx;
+        const unsigned sy = divmod_u32(sub, job.div_supersampling, sx);
+        return start_sample_at(sc, job, L, x, y, yc, s, hue, sub, sx, sy);
+    }
     if (job.sched != nullptr) {
         // block = (sample, group of group_tiles consecutive tiles): sample-major
         const unsigned long long blk = q / job.group_tiles;
@@ -820,6 +835,11 @@ RT_DEV bool start_sample(const DevScene& sc, const DevJob& job, unsigned long lo
     const unsigned hues = sc.dispersion ? 8u : 1u;
     const unsigned hue = s % hues, sub = s / hues;
     const unsigned sx = sub % sc.supersampling, sy = sub / sc.supersampling;
+    return start_sample_at(sc, job, L, x, y, yc, s, hue, sub, sx, sy);
+}
+
+// ... the camera ray of sample s (= hue, sub-pixel (sx, sy)) of pixel (x, y), row yc of the compact output
+RT_DEV bool start_sample_at(const DevScene& sc, const DevJob& job, Lane& L, unsigned x, unsigned y, unsigned yc, unsigned s, unsigned hue, unsigned sub, unsigned sx, unsigned sy) {
     const float sdx = sc.sub_disp[sx], sdy = sc.sub_disp[sy];
     const V3 on_plane = {sc.ray_x[x] + sdx * sc.pixel_size[0], sc.ray_y[y] + sdy * sc.pixel_size[1], -1.0f};
     const V3 on_focus = xform_point(sc.cam, on_plane * sc.focus_distance);

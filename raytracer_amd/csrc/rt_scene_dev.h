@@ -6,6 +6,7 @@
 #pragma once
 
 #include <stdint.h>
+#include "rt_divide.h"
 
 namespace rtd {
 
@@ -202,7 +203,11 @@ struct DevJob {
     uint32_t hot_steps;          // a march of a first sample that reaches this many steps makes its tile hot
     uint32_t group_tiles;        // tiles per block under `sched` (a wave's fetch costs three or four round trips to memory: fewer, larger blocks)
     uint32_t n_groups;           // ceil(n_tiles / group_tiles)
-    uint32_t pad0;
+    // start_sample's divisors, fixed for the launch (rt_divide.h): a sample id is taken apart with five multiplications
+    // instead of a 64-bit and four 32-bit divisions (some 250 VALU instructions per sample, 4 % of C2's).  fast_decode is
+    // off when an id's block number does not fit 32 bits (a frame of 2^38 samples).
+    uint32_t fast_decode;
+    DevDiv div_samples, div_tiles_x, div_band_rows, div_supersampling;
 };
 constexpr uint32_t kSchedHeaderWords = 8;
 constexpr uint32_t kSchedLevels = 3;     // a march that reaches hot_steps << k steps puts its tile on list k
