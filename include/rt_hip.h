@@ -304,7 +304,10 @@ int rt_photon_generate_part_device(rt_ctx* ctx, void* hip_stream, uint32_t part,
  * the reference's order (*ordered_out = 1), or not (0: RT_OPT_PHOTON_ORDER is off, the key did not fit 64 bits, or
  * the pass outgrew the record buffer and its surplus was added with atomics — the buffer has then been resized and
  * enqueueing the pass again gives the ordered result).  For callers of the asynchronous entry points that want the
- * guarantee rt_photon_generate gives by itself.  No counterpart in the reference (its pass is sequential). */
+ * guarantee rt_photon_generate gives by itself.  RT_ERR_HIP with a message if the ordered sum met a record or a run
+ * outside its buffers (the kernels check every segment before they touch it; never seen with sound bookkeeping: an
+ * internal error, the textures of that pass are incomplete) — rt_photon_generate reports the same.
+ * No counterpart in the reference (its pass is sequential). */
 int rt_photon_ordered(rt_ctx* ctx, int* ordered_out);
 int rt_photon_atlas_device(rt_ctx* ctx, void** d_atlas_out, uint64_t* n_floats_out);
 
