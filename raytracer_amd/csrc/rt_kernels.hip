@@ -471,15 +471,17 @@ RT_DEV const DevSphere* sphere_of_object(const DevScene& sc, unsigned obj) {
     }
     return nullptr;
 }
+// (out of line: rare, and inlined it costs the shader waves of trace_julia_kernel registers they spill)
+__device__ __attribute__((noinline)) bool sphere_hit_within(const DevSphere* sphere, V3 o, V3 d, float maxd) {
+    HitRec again;
+    return sphere_intersect(sphere, o, d, maxd, again);
+}
 RT_DEV void accept_julia_hit(const DevScene& sc, Lane& L, const HitRec& h, const DevJulia& j, const DevMaterial& m) {
     if (L.qkind != Q_SHADOW) {
         bool nearer = h.dist < L.qmax || (h.dist == L.qmax && (!L.found || j.object > L.best_obj));
         if (L.found != 0u && L.best_obj > j.object && L.best_tri == kNoTriangle) {
             // (an unseen back face of the set changes nothing in the reference's loop: accept_hit below drops it either way)
-            if (const DevSphere* sphere = sphere_of_object(sc, L.best_obj)) {
-                HitRec again;
-                nearer = !sphere_intersect(sphere, L.qo, L.qd, h.dist, again);
-            }
+            if (const DevSphere* sphere = sphere_of_object(sc, L.best_obj)) nearer = !sphere_hit_within(sphere, L.qo, L.qd, h.dist);
         }
         if (!nearer) return;
     }
