@@ -542,8 +542,8 @@ bool deposit_overflow_seen(rt_ctx* ctx) {
 int deposit_buffers(rt_ctx* ctx, unsigned long long all_roots, unsigned key_bits, unsigned long long n_texels, hipStream_t stream) {
     (void)deposit_overflow_seen(ctx);
     if (ctx->dep_capacity == 0) {
-        // C5: 8.0 M roots leave 0.37 M deposits (+ 0.05 M slots that stay unused: a wave reserves records kDepositChunk at a time)
-        const unsigned long long guess = std::max<unsigned long long>(1ull << 18, all_roots / 16);
+        // C5: 8.0 M roots leave 0.37 M deposits (+ 0.08 M slots that stay unused: a wave reserves records kDepositChunk at a time)
+        const unsigned long long guess = std::max<unsigned long long>(1ull << 18, all_roots / 12);
         ctx->dep_capacity = static_cast<uint32_t>(std::min<unsigned long long>((guess + 65535ull) & ~65535ull, 1ull << 31));
     }
     const size_t n = ctx->dep_capacity;

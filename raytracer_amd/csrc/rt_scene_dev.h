@@ -262,7 +262,10 @@ struct DevPhotonJob {
 #else
 #define RT_GUARD_OK(words, site, index, limit) true
 #endif
-constexpr uint32_t kDepositChunk = 32;      // records a wave reserves per atomic
+#ifndef RT_DEPOSIT_CHUNK
+#define RT_DEPOSIT_CHUNK 64      // [MI355X, C5] photon_kernel 245 us at 32, 234 at 64, 232 at 128, 230 at 256 (tools/photon_chunk_ab.sh); a wave leaves half a chunk unused
+#endif
+constexpr uint32_t kDepositChunk = RT_DEPOSIT_CHUNK;      // records a wave reserves per atomic (one counter for the whole chip)
 constexpr uint32_t kDepositLongRun = 32;    // deposits into one texel from which a wave sums them (rt_photon_order.hip)
 
 // Shape of trace_julia_kernel's workgroup (rt_kernels.hip), shared with the launch code
