@@ -1,5 +1,6 @@
 #!/bin/bash
-# Developer A/B (GPU box): SQ and TCP counters of photon_kernel on the C5 bench workload, RT_PHOTON_FORK=1 against 0.
+# Developer A/B (GPU box): SQ and TCP counters of photon_kernel on the C5 bench workload, RT_PHOTON_FORK=1 against 0
+# (the switch of tools/experiments/r03_photon_fork.patch, measured and not kept: apply the patch first).
 cd /tmp && export TMPDIR=/tmp
 for f in 1 0; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_photon_fork$f
