@@ -442,6 +442,8 @@ def main():
     ap.add_argument("--extra-reps", type=int, default=3)
     ap.add_argument("--bvh-min", type=int, default=None, help="developer: RT_OPT_BVH_MIN_TRIANGLES before the upload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-call-output", action="store_true",
+                    help="developer: rt_render_device + rt_quantize_device per step instead of rt_render_rgba8_device (same bytes)")
     args = ap.parse_args()
     claim_stdout()
 
@@ -536,10 +538,14 @@ def main():
             ctx.photon_generate_device(stream)
         if events is not None:
             events[0].record()
-        ctx.render_device(frame.data_ptr(), stream)
+        if args.two_call_output:
+            ctx.render_device(frame.data_ptr(), stream)
+        else:       # the picture leaves the kernel as Color::scaleOut bytes (rt_render_rgba8_device)
+            ctx.render_rgba8_device(frame8[buf].data_ptr(), stream)
         if events is not None:
             events[1].record()
-        ctx.quantize_device(frame.data_ptr(), frame8[buf].data_ptr(), 1.0, n_pix, stream)
+        if args.two_call_output:
+            ctx.quantize_device(frame.data_ptr(), frame8[buf].data_ptr(), 1.0, n_pix, stream)
         if world > 1:
             pending[buf] = dist.gather(frame8[buf], gathered[buf], dst=0, async_op=True)
 

@@ -265,6 +265,7 @@ def hip_lib():
         lib.rt_render.argtypes = [C.c_void_p, C.POINTER(Bands), C.c_void_p, C.POINTER(Stats)]
         lib.rt_render_device.argtypes = [C.c_void_p, C.POINTER(Bands), C.c_void_p, C.c_void_p]
         lib.rt_render_device_noalloc.argtypes = [C.c_void_p, C.POINTER(Bands), C.c_void_p, C.c_void_p]
+        lib.rt_render_rgba8_device.argtypes = [C.c_void_p, C.POINTER(Bands), C.c_float, C.c_void_p, C.c_void_p]
         lib.rt_photon_generate_device.argtypes = [C.c_void_p, C.c_void_p]
         lib.rt_photon_generate_part_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         lib.rt_photon_atlas_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
@@ -333,6 +334,11 @@ class Context:
     def render_device(self, d_out_ptr, stream=None, bands=None):
         self._check(self._lib.rt_render_device(self._ctx, C.byref(bands) if bands else None, C.c_void_p(d_out_ptr),
                                                C.c_void_p(stream or 0)), "rt_render_device")
+
+    def render_rgba8_device(self, d_out8_ptr, stream=None, bands=None, gain=1.0):
+        """rt_render_device + rt_quantize_device in one: the RGBA8 picture only (device memory, 4 bytes per pixel)."""
+        self._check(self._lib.rt_render_rgba8_device(self._ctx, C.byref(bands) if bands else None, gain, C.c_void_p(d_out8_ptr),
+                                                     C.c_void_p(stream or 0)), "rt_render_rgba8_device")
 
     def render_device_noalloc(self, d_out_ptr, stream=None, bands=None):
         self._check(self._lib.rt_render_device_noalloc(self._ctx, C.byref(bands) if bands else None, C.c_void_p(d_out_ptr),

@@ -27,7 +27,7 @@ __global__ void trace_julia_kernel(const DevScene sc, const DevJob job);
 template <bool HAS_JULIA, bool STATS>
 __global__ void photon_kernel(const DevScene sc, const DevPhotonJob job);
 __global__ void photon_cull_kernel(const DevScene sc, const DevPhotonJob job, unsigned n_dirs, uint32_t* live_dirs, unsigned long long* live_count);
-__global__ void sum_samples_kernel(const float4* samples, float4* out, unsigned long long n_pixels, unsigned samples_per_pixel, float inv_samples);
+__global__ void sum_samples_kernel(const float4* samples, float4* out, unsigned long long n_pixels, unsigned samples_per_pixel, float inv_samples, uchar4* out8, float gain);
 __global__ void kat_intersect_kernel(const DevScene sc, const unsigned* kind, const unsigned* prim, const float* rays, unsigned n, float* out);
 __global__ void kat_fresnel_kernel(const float* in, unsigned n, float* out);
 __global__ void mul_add_kernel(float* acc, const float* src, float factor, unsigned long long n);
@@ -349,7 +349,9 @@ int persistent_grid(rt_ctx* ctx, K kernel, uint64_t work_items, int* blocks, siz
 // Enqueues one render.  `fixed` == NULL: the context's own buffers, grown on demand (hipMalloc).  Otherwise the launch
 // is fitted into the given workspace and nothing is allocated: fewer persistent workgroups when the frame stacks of
 // a full grid do not fit, RT_ERR_LIMIT when not even one workgroup or the sample buffer fits.
-int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_t stream, const Workspace* fixed = nullptr) {
+// d_out8 != NULL: the quantised picture (Color::scaleOut with `gain`) is written instead of the float one — by the trace
+// kernel itself where a pixel has one sample, by sum_samples_kernel otherwise; d_out is not touched then.
+int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_t stream, const Workspace* fixed = nullptr, uchar4* d_out8 = nullptr, float gain = 1.0f) {
     if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_render before rt_scene_upload");
     if (bands && (bands->band_rows == 0 || bands->band_stride == 0)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_bands: band_rows and band_stride must be > 0");
     DevJob job;
@@ -430,7 +432,9 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     }
     job.sched = ws.sched;
     job.hot_steps = ctx->julia_hot_steps;
-    job.out = d_out;
+    job.out = d_out8 != nullptr ? nullptr : d_out;
+    job.out8 = d_out8;
+    job.out8_gain = gain;
     job.id_chunk = 1;   // see fetch_ids
     // waves that draw sample ids: every wave of trace_kernel, the shader waves of trace_julia_kernel
     const uint64_t id_lanes = julia ? static_cast<uint64_t>(blocks) * kJuliaShaderWavesHost * 64 : lanes;
@@ -481,7 +485,7 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     RT_HIP_TRY(ctx, hipGetLastError());
     if (job.samples_per_pixel > 1) {
         const unsigned g = static_cast<unsigned>((job.n_pixels + 255) / 256);
-        hipLaunchKernelGGL(sum_samples_kernel, dim3(g), dim3(256), 0, stream, job.samples, job.out, job.n_pixels, job.samples_per_pixel, ctx->dev.inv_samples);
+        hipLaunchKernelGGL(sum_samples_kernel, dim3(g), dim3(256), 0, stream, job.samples, job.out, job.n_pixels, job.samples_per_pixel, ctx->dev.inv_samples, job.out8, job.out8_gain);
         RT_HIP_TRY(ctx, hipGetLastError());
     }
     if (julia) {
@@ -1501,11 +1505,18 @@ int rt_render_rgba8(rt_ctx* ctx, const rt_bands* bands, uint8_t* rgba8_out, floa
     RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint64_t n_pixels = rt_bands_pixel_count(ctx->dev.width, ctx->dev.height, bands);
     if (n_pixels == 0) return read_stats(ctx, stats);
-    int rc = grow(ctx, ctx->out_staging, n_pixels * sizeof(float4));
+    int rc = grow(ctx, ctx->out8, n_pixels * 4);
     if (rc != RT_OK) return rc;
-    if ((rc = render_enqueue(ctx, bands, static_cast<float4*>(ctx->out_staging.ptr), nullptr)) != RT_OK) return rc;
-    if ((rc = download_rgba8(ctx, static_cast<const float4*>(ctx->out_staging.ptr), n_pixels, gain, rgba8_out)) != RT_OK) return rc;
+    if ((rc = render_enqueue(ctx, bands, nullptr, nullptr, nullptr, static_cast<uchar4*>(ctx->out8.ptr), gain)) != RT_OK) return rc;
+    if ((rc = download(ctx, rgba8_out, ctx->out8.ptr, n_pixels * 4)) != RT_OK) return rc;
     return read_stats(ctx, stats);
+}
+
+int rt_render_rgba8_device(rt_ctx* ctx, const rt_bands* bands, float gain, void* d_rgba8_out, void* hip_stream) {
+    if (ctx == nullptr) return RT_ERR_INVALID_ARGUMENT;
+    if (d_rgba8_out == nullptr) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render_rgba8_device: output pointer is NULL");
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return render_enqueue(ctx, bands, nullptr, static_cast<hipStream_t>(hip_stream), nullptr, static_cast<uchar4*>(d_rgba8_out), gain);
 }
 
 int rt_render_accumulate(rt_ctx* ctx, const rt_bands* bands, float weight, int first) {

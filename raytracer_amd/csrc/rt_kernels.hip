@@ -864,6 +864,15 @@ RT_DEV bool start_sample_at(const DevScene& sc, const DevJob& job, Lane& L, unsi
     return true;
 }
 
+// Color::scaleOut (src/types.h:274-282): u8(clamp(v * gain, 0, 1) * 255.0f), truncating; NaN -> 0 like the x86 cast.
+RT_DEV uchar4 scale_out(float4 c, float gain) {
+    auto q = [gain](float v) -> unsigned char {
+        const float s = clampf(v * gain, 0.0f, 1.0f) * 255.0f;
+        return static_cast<unsigned char>(s != s ? 0.0f : s);
+    };
+    return make_uchar4(q(c.x), q(c.y), q(c.z), q(c.w));
+}
+
 // Stores a finished primary sample (src/raytracer.cpp:100-110).
 RT_DEV void store_sample(const DevScene& sc, const DevJob& job, const Lane& L, Col value) {
     Col contrib = value;
@@ -874,7 +883,8 @@ RT_DEV void store_sample(const DevScene& sc, const DevJob& job, const Lane& L, C
     if (job.samples_per_pixel == 1) {
         const Col zero = {0.0f, 0.0f, 0.0f, 0.0f};
         const Col px = zero + (zero + contrib) * sc.inv_samples;
-        job.out[L.out_slot] = make_float4(px.r, px.g, px.b, px.a);
+        if (job.out8 != nullptr) job.out8[L.out_slot] = scale_out(make_float4(px.r, px.g, px.b, px.a), job.out8_gain);
+        else job.out[L.out_slot] = make_float4(px.r, px.g, px.b, px.a);
     } else {
         job.samples[L.out_slot] = make_float4(contrib.r, contrib.g, contrib.b, contrib.a);
     }
@@ -2653,7 +2663,8 @@ __global__ __launch_bounds__(kJuliaWaves * 64, kJuliaWaves / 4) void trace_julia
 
 // ---- per-pixel sum of the samples, in the reference's order (src/raytracer.cpp:61-110) ------------
 __global__ __launch_bounds__(256) void sum_samples_kernel(const float4* __restrict__ samples, float4* __restrict__ out,
-                                                          unsigned long long n_pixels, unsigned samples_per_pixel, float inv_samples) {
+                                                          unsigned long long n_pixels, unsigned samples_per_pixel, float inv_samples,
+                                                          uchar4* __restrict__ out8, float gain) {
     const unsigned long long p = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (p >= n_pixels) return;
     Col rad = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -2663,7 +2674,8 @@ __global__ __launch_bounds__(256) void sum_samples_kernel(const float4* __restri
     }
     const Col zero = {0.0f, 0.0f, 0.0f, 0.0f};
     const Col px = zero + rad * inv_samples;
-    out[p] = make_float4(px.r, px.g, px.b, px.a);
+    if (out8 != nullptr) out8[p] = scale_out(make_float4(px.r, px.g, px.b, px.a), gain);      // (the quantised picture only)
+    else out[p] = make_float4(px.r, px.g, px.b, px.a);
 }
 
 // ---- photon roots that can leave nothing (DevScene::photon_cull_*) ----------------------------------------------
@@ -3029,12 +3041,7 @@ __global__ __launch_bounds__(256) void mul_add_kernel(float* __restrict__ acc, c
 __global__ __launch_bounds__(256) void quantize_kernel(const float4* __restrict__ rgba, uchar4* __restrict__ out, float gain, unsigned long long n) {
     const unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float4 c = rgba[i];
-    auto q = [gain](float v) -> unsigned char {
-        const float s = clampf(v * gain, 0.0f, 1.0f) * 255.0f;
-        return static_cast<unsigned char>(s != s ? 0.0f : s);   // truncation; NaN -> 0 like the x86 cast
-    };
-    out[i] = make_uchar4(q(c.x), q(c.y), q(c.z), q(c.w));
+    out[i] = scale_out(rgba[i], gain);
 }
 
 // explicit instantiations used by rt_api.hip

@@ -180,7 +180,10 @@ struct DevJob {
     uint64_t n_samples;          // tiles_x*tiles_y*samples_per_pixel*64 (incl. padding lanes of edge tiles)
     uint64_t n_pixels;           // compact_rows*width
     float4* samples;             // [samples_per_pixel][n_pixels] or NULL when samples_per_pixel == 1
-    float4* out;                 // [n_pixels]
+    float4* out;                 // [n_pixels], or NULL when the caller wants the quantised picture only:
+    uchar4* out8;                // [n_pixels] Color::scaleOut of the pixel with gain out8_gain (src/types.h:274-282), or NULL
+    float out8_gain;
+    uint32_t pad_out8;
     float* stack;                // per-lane DFS frames: [frame][field][grid lane]
     unsigned long long* queue_head;
     unsigned long long* counters;// rt_stats words (only touched when STATS)

@@ -626,6 +626,44 @@ def test_mul_add_and_quantize_device(hip_ctx):
     assert np.array_equal(q.cpu().numpy(), capi.quantize(a + b * f))      # Color::scaleOut
 
 
+@pytest.mark.parametrize("source,size,supersampling,bands", [
+    ("examples/example1.xml", (200, 120), 1, None),            # one sample per pixel: the trace kernel quantises
+    ("examples/example1.xml", (96, 64), 2, None),              # several: the kernel that sums them does
+    ("examples2/4_julia.xml", (96, 64), 1, None),              # the Julia kernel's shader waves
+    ("examples3/103_caustic_steps200.xml", (160, 120), 1, (8, 1, 3)),   # a band share, photon textures read
+])
+def test_render_rgba8_device_is_render_then_quantize(hip_ctx, source, size, supersampling, bands):
+    """rt_render_rgba8_device (the picture leaves the kernel as Color::scaleOut bytes, src/types.h:274-282) against
+    rt_render_device + rt_quantize_device, and against scaleOut of the oracle's float picture."""
+    import torch
+    sc = capi.Scene(scene_path(source), 0.0)
+    sc.set_camera(size[0], size[1], supersampling)
+    hip_ctx.upload(sc)
+    if sc.desc.photon_steps > 0:
+        hip_ctx.photon_generate()
+    b = capi.Bands(*bands) if bands else None
+    n = hip_ctx.pixel_count(b)
+    stream = torch.cuda.current_stream().cuda_stream
+    rgba = torch.empty((n, 4), dtype=torch.float32, device="cuda:0")
+    two = torch.empty((n, 4), dtype=torch.uint8, device="cuda:0")
+    one = torch.full((n + 16, 4), 0x5A, dtype=torch.uint8, device="cuda:0")      # (16 pixels of canary behind the picture)
+    hip_ctx.render_device(rgba.data_ptr(), stream, b)
+    hip_ctx.quantize_device(rgba.data_ptr(), two.data_ptr(), 1.0, n, stream)
+    hip_ctx.render_rgba8_device(one.data_ptr(), stream, b)
+    torch.cuda.synchronize()
+    hip_ctx.launch_status()
+    assert np.array_equal(one[:n].cpu().numpy(), two.cpu().numpy())
+    assert (one[n:].cpu().numpy() == 0x5A).all()
+    if bands is None:
+        ref, _ = oracle_lib.render(sc, None, threads=16)
+        assert np.array_equal(one[:n].cpu().numpy(), capi.quantize(ref.reshape(-1, 4)))
+    # a gain other than 1 reaches both kernels
+    hip_ctx.quantize_device(rgba.data_ptr(), two.data_ptr(), 0.5, n, stream)
+    hip_ctx.render_rgba8_device(one.data_ptr(), stream, b, gain=0.5)
+    torch.cuda.synchronize()
+    assert np.array_equal(one[:n].cpu().numpy(), two.cpu().numpy())
+
+
 # ---- the callers either side of the path: CLI loops and the driver ---------------------------------
 
 def test_cli_renders_the_caustic_animation_like_the_reference(tmp_path):
