@@ -460,8 +460,12 @@ def main():
     if rehearsal:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # RT_BENCH_FORCE_GATHER=1: a one-rank run goes through the process group and the gathers too (hardware test of the
+    # N > 1 step's RCCL calls on a one-GPU box; developer switch, the line then says so in config.parallelism)
+    collective = world > 1 or os.environ.get("RT_BENCH_FORCE_GATHER", "0") not in ("", "0")
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -491,7 +495,7 @@ def main():
     frame = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
     # two RGBA8 frames: the gather of step i runs on RCCL's stream while step i+1 renders
     frame8 = [torch.empty((h, w, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
-    gathered = [[torch.empty_like(frame8[0]) for _ in range(world)] for _ in range(2)] if (world > 1 and rank == 0) else [None, None]
+    gathered = [[torch.empty_like(frame8[0]) for _ in range(world)] for _ in range(2)] if (collective and rank == 0) else [None, None]
     pending = [None, None]
     stream = torch.cuda.current_stream().cuda_stream
     has_photons = scene.desc.photon_steps > 0
@@ -546,7 +550,7 @@ def main():
             events[1].record()
         if args.two_call_output:
             ctx.quantize_device(frame.data_ptr(), frame8[buf].data_ptr(), 1.0, n_pix, stream)
-        if world > 1:
+        if collective:
             pending[buf] = dist.gather(frame8[buf], gathered[buf], dst=0, async_op=True)
 
     def fence():
@@ -554,7 +558,7 @@ def main():
             if pending[b] is not None:
                 pending[b].wait()
                 pending[b] = None
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -569,7 +573,7 @@ def main():
         step(i, events[i])
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if collective:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -602,7 +606,7 @@ def main():
                        "shadow_rays_elided_per_frame": stats.get("shadow_rays_elided", 0),   # counted in rays_per_frame (rays of the reference's formulation), not traced: DESIGN.md 4.4
                        "rays_traced_per_frame": rays_traced,   # what the plain launch traces
                        "frames_per_step": world, "sec_per_frame": elapsed / args.steps,
-                       "parallelism": "frames sharded over ranks, RGBA8 frames gathered to rank 0 over RCCL (gather of a step overlaps the next step's render; all gathers complete inside the timed region)" if world > 1 else "1 GPU"},
+                       "parallelism": "frames sharded over ranks, RGBA8 frames gathered to rank 0 over RCCL (gather of a step overlaps the next step's render; all gathers complete inside the timed region)" if world > 1 else ("1 GPU, RT_BENCH_FORCE_GATHER: the frame gathered to itself over RCCL" if collective else "1 GPU")},
             "roofline": {"bound": "valu", "kernel": "trace_julia_kernel" if scene.desc.n_julias > 0 else "trace_kernel", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": measured_traffic(args.workload),
                          "executed_valu": executed_valu(args.workload, kernel_ms),
@@ -623,7 +627,7 @@ def main():
                     extra["c5_cpu_reference"] = ref
             line["extra"] = extra
         emit(line)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

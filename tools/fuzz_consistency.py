@@ -2,7 +2,7 @@
 """Developer tool (GPU box): tools/fuzz_consistency.py FIRST LAST  -> on the seeded random scenes of tests/mesh_scene.py, the
 HIP path against ITSELF through its other doors (no oracle, so thousands of scenes per minute): the whole picture against
 the picture assembled from rt_bands{8, r, 3} for r = 0..2, against rt_render_device_noalloc, against a second render,
-and the photon textures of two passes.  Everything must be the same bits."""
+against rt_render_rgba8_device (Color::scaleOut of it), and the photon textures of two passes.  Everything must be the same bits."""
 import os
 import pathlib
 import sys
@@ -55,6 +55,12 @@ def main():
         except capi.RtError as e:
             if "exceed" not in str(e) and "fit" not in str(e):      # (a frame beyond the fixed workspace is a documented limit)
                 why.append("noalloc: %s" % e)
+        out8 = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
+        ctx.render_rgba8_device(out8.data_ptr())
+        torch.cuda.synchronize()
+        ctx.launch_status()
+        if not np.array_equal(out8.cpu().numpy().reshape(-1, 4), capi.quantize(img.reshape(-1, 4))):
+            why.append("rgba8")
         if tex:
             ctx.photon_generate()
             for o in range(sc.desc.n_objects):
