@@ -533,11 +533,19 @@ def main():
             flops_note = "BVH scene: flops of the executed traversal (node visits, leaf tests) x bench.py:FLOPS"
     ctx.set_option(capi.RT_OPT_COLLECT_STATS, 0)
 
+    trace_steps = os.environ.get("RT_BENCH_TRACE_STEPS", "0") not in ("", "0")     # developer: host time of a step's calls on stderr
+
     def step(i, events=None):
         buf = i % 2
+        if trace_steps:      # a step that does not return within 30 s leaves the stack of every Python thread on stderr
+            import faulthandler
+            faulthandler.cancel_dump_traceback_later()
+            faulthandler.dump_traceback_later(30, repeat=False, file=sys.stderr)
+        t_in = time.perf_counter()
         if pending[buf] is not None:
             pending[buf].wait()          # the frame gathered two steps ago has left this buffer
             pending[buf] = None
+        t_waited = time.perf_counter()
         if has_photons:
             ctx.photon_generate_device(stream)
         if events is not None:
@@ -550,8 +558,13 @@ def main():
             events[1].record()
         if args.two_call_output:
             ctx.quantize_device(frame.data_ptr(), frame8[buf].data_ptr(), 1.0, n_pix, stream)
+        t_enqueued = time.perf_counter()
         if collective:
+            driver.settle_for_gloo(frame8[buf])      # (rehearsals over gloo only: see there)
             pending[buf] = dist.gather(frame8[buf], gathered[buf], dst=0, async_op=True)
+        if trace_steps:
+            progress("step %d: wait for the gather of two steps ago %.3f ms, enqueue %.3f ms, gather call %.3f ms" % (
+                i, (t_waited - t_in) * 1e3, (t_enqueued - t_waited) * 1e3, (time.perf_counter() - t_enqueued) * 1e3))
 
     def fence():
         for b in range(2):

@@ -184,12 +184,23 @@ def world_info():
     return 0, 1
 
 
+def settle_for_gloo(tensor):
+    """Rehearsal only (RT_DIST_BACKEND=gloo with device tensors).  torch 2.10's gloo backend on ROCm 7.2 hangs in
+    Work.wait() when a DEVICE tensor is handed to an asynchronous collective while kernels are still in flight on the
+    current stream and the host goes on submitting: its worker thread never returns from waiting for the staging copy.
+    tools/gloo_cuda_gather_probe.py shows it with torch kernels alone (`torch-long`), nothing of this package loaded;
+    with the device idle at the call it does not happen.  RCCL, the product path, has no such thread and is not touched."""
+    if tensor.is_cuda and dist.is_initialized() and dist.get_backend() == "gloo":
+        torch.cuda.synchronize(tensor.device)
+
+
 def gather_to_root(tensor):
     """Returns the list of every rank's tensor on rank 0 (None elsewhere).  Equal shapes required."""
     rank, world = world_info()
     if world == 1:
         return [tensor]
     out = [torch.empty_like(tensor) for _ in range(world)] if rank == 0 else None
+    settle_for_gloo(tensor)
     dist.gather(tensor, out, dst=0)
     return out
 
@@ -258,6 +269,7 @@ def render_still(renderer, scene):
         # of the root photons, the deposits of all slices are summed into every rank's textures
         atlas = renderer.photon_pass(scene, rank, world)
         if atlas is not None:
+            settle_for_gloo(atlas)
             dist.all_reduce(atlas, op=dist.ReduceOp.SUM)
         part = renderer.render(scene, bands, photons_ready=True)
     else:
@@ -347,6 +359,7 @@ def render_units(renderer, path, units, consume, payload=None):
                 # fresh tensors every round (the caching allocator makes that cheap): consumers may still be reading
                 # the previous ones on another stream (HostFrames), which record_stream keeps alive, not unwritten
                 gathered[b] = [torch.empty_like(out) for _ in range(world)]
+            settle_for_gloo(out)
             pending[b] = dist.gather(out, gathered[b] if rank == 0 else None, dst=0, async_op=True)
 
     def confirm_up_to(last):

@@ -1,9 +1,11 @@
 #!/bin/bash
 # developer tool (GPU box with ONE GPU): the torch driver with two ranks sharing the GPU, collectives through gloo
 # (RT_DIST_BACKEND=gloo), on small variants of the caustic animation (plain and motion blur) and a Julia still: the files must
-# be the single-process ones, byte for byte.  Two processes on one GPU take turns at it, so this is slow for what it renders
-# (and bench.py --gpus 2 with its full-size frames is not a usable rehearsal: two persistent grids sharing the GPU took 1 s per
-# 1.8 ms step when they ran at all).
+# be the single-process ones, byte for byte.  Two processes on one GPU take turns at it, so this is slow for what it renders.
+# (Round 2 noted that bench.py --gpus 2 over gloo "took 1 s per 1.8 ms step when it ran at all" and blamed the two grids
+# sharing the GPU.  It was torch's gloo backend: handed a device tensor while kernels are in flight it hangs in Work.wait(),
+# with one rank and torch kernels alone too — tools/gloo_cuda_gather_probe.py, DESIGN.md 5.  driver.settle_for_gloo waits for
+# the device before such a call; since then `RT_DIST_BACKEND=gloo torchrun --nproc-per-node 2 bench.py --gpus 2` runs.)
 set -e
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/rehearse; mkdir -p $OUT
