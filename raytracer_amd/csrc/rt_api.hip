@@ -453,18 +453,13 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     job.debug_abort = ctx->debug_force_abort ? 1u : 0u;
     job.elide_unlit = (ctx->elide_unlit_shadows && !stats) ? 1u : 0u;
     if (ctx->upload_in_flight && stream != nullptr) RT_HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ev_upload, 0));   // the scene's copy ran on the default stream
-    if (fixed != nullptr) {
-        // the fixed workspace is shared by every call on this GPU and keeps the last call's contents: the queue head
-        // and the counters start at zero (the frame stacks and the sample buffer are written before they are read).
-        // Word [1], the watchdog flag, is sticky here too: cleared only once a host has seen it (launch_status), so
-        // that two launches without rt_launch_status in between do not lose the first one's abandonment
-        RT_HIP_TRY(ctx, hipMemsetAsync(ws.queue, 0, sizeof(unsigned long long), stream));
-        RT_HIP_TRY(ctx, hipMemsetAsync(ws.counters, 0, C_COUNT * sizeof(unsigned long long), stream));
-    } else {
-        // [0] queue head: cleared per launch.  [1] watchdog flag: sticky, cleared only once the host has seen it (launch_status)
-        RT_HIP_TRY(ctx, hipMemsetAsync(ws.queue, 0, sizeof(unsigned long long), stream));
-        RT_HIP_TRY(ctx, hipMemsetAsync(ws.counters, 0, C_COUNT * sizeof(unsigned long long), stream));
-    }
+    // Both workspaces (the context's own and the fixed one of the no-alloc entry point, which every call on this GPU
+    // shares) keep the last call's contents: the queue head [0] and the counters start at zero, the frame stacks and the
+    // sample buffer are written before they are read.  Word [1], the watchdog flag, is sticky: cleared only once a host
+    // has seen it (launch_status), so that two launches without rt_launch_status in between do not lose the first one's
+    // abandonment
+    RT_HIP_TRY(ctx, hipMemsetAsync(ws.queue, 0, sizeof(unsigned long long), stream));
+    RT_HIP_TRY(ctx, hipMemsetAsync(ws.counters, 0, C_COUNT * sizeof(unsigned long long), stream));
     if (job.sched != nullptr) {
         RT_HIP_TRY(ctx, hipMemsetAsync(job.sched, 0, sched_zero_words * sizeof(uint32_t), stream));
         RT_HIP_TRY(ctx, hipMemsetAsync(job.sched + sched_zero_words, 0xff, sched_list_words * sizeof(uint32_t), stream));
@@ -623,7 +618,7 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
         job.id_chunk = id_chunk_for(job.n_roots - job.dyn_base, lanes);
         job.queue_head = ctx->d_queue;
         job.counters = ctx->d_counters;
-        RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 2 * sizeof(unsigned long long), stream));
+        RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), stream));   // the head only: [1] is the Julia watchdog's sticky flag
         RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_dep_words, 0, 16 * sizeof(unsigned long long), stream));   // every control word of the pass at once
         // reference deposit order: record, sort, sum (rt_photon_order.hip) when the key fits 64 bits
         const unsigned long long n_texels = static_cast<unsigned long long>(ctx->n_slots) * ctx->dev.photon_size * ctx->dev.photon_size;
