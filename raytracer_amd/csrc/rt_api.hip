@@ -98,7 +98,10 @@ struct Workspace {
 constexpr size_t kNoAllocScratchBytes = size_t(RT_NOALLOC_SCRATCH_BYTES);
 constexpr size_t kNoAllocHeaderBytes = 4096;   // queue words at 0, counters at 256
 static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
-static_assert(C_COUNT * sizeof(unsigned long long) + 256 <= kNoAllocHeaderBytes, "scratch header");
+// the counter words, padded so that clearing them is one fill kernel (hipMemsetAsync splits a size that is no multiple of
+// its wide store into a body and a tail: two launches, 5 us each, per render and per photon pass)
+constexpr size_t kCounterBytes = (C_COUNT * sizeof(unsigned long long) + 255) & ~size_t(255);
+static_assert(kCounterBytes + 256 <= kNoAllocHeaderBytes, "scratch header");
 
 }  // namespace
 
@@ -145,7 +148,7 @@ struct rt_ctx {
     Buffer live_dirs;                            // RT_OPT_CULL_PHOTON_ROOTS: the directions of the photon pass that may meet a specular object
     uint32_t dep_capacity = 0;         // records; 0 = choose from the number of roots
     size_t dep_temp_bytes = 0;
-    unsigned long long* d_dep_words = nullptr;   // [0] records reserved, [1] deposits that found the buffer full, [2] long runs, [3] deposits beyond a root's key field, [4] live directions (photon_cull_kernel), [5] photon_order_bucket's cursor, [6] records or runs it found outside the record buffer (internal error), [8..10] developer build RT_GUARD: first index violation (site, index, limit)
+    unsigned long long* d_dep_words = nullptr;   // [0] records reserved, [1] deposits that found the buffer full, [2] long runs, [3] deposits beyond a root's key field, [4] live directions (photon_cull_kernel), [5] photon_order_bucket's cursor, [6] records or runs it found outside the record buffer (internal error), [8..10] developer build RT_GUARD: first index violation (site, index, limit), [16] the pass's queue head
     unsigned long long* h_dep_words = nullptr;   // pinned copy, written by the stream after every ordered pass
     hipEvent_t ev_dep = nullptr;
     bool dep_check_pending = false;
@@ -173,7 +176,8 @@ struct rt_ctx {
     int trace_blocks_per_cu[2] = {0, 0};
     int dense_blocks_per_cu[2] = {0, 0};       // trace_kernel<.., DENSE>: 4 when the scene allows it, else 0 (never used)
     int julia_blocks_per_cu[2] = {0, 0};
-    unsigned long long* d_counters = nullptr;   // rt_stats words
+    unsigned long long* d_counters = nullptr;   // rt_stats words (kCounterBytes)
+    bool counters_clean = false;                // all zero, and nothing enqueued that writes them: only counters launches (RT_OPT_COLLECT_STATS) do
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool events_pending = false;
 };
@@ -346,6 +350,18 @@ int persistent_grid(rt_ctx* ctx, K kernel, uint64_t work_items, int* blocks, siz
     return RT_OK;
 }
 
+// Clears the counter words for a launch.  The context's own are cleared only when a counters launch has written them
+// since, or is about to: the product kernels never touch them (three fill kernels fewer per frame of C5).
+int clear_counters(rt_ctx* ctx, unsigned long long* counters, bool stats, hipStream_t stream) {
+    const bool own = counters == ctx->d_counters;
+#ifndef RT_PHASE_TIMING      // (that developer build adds its clocks to the words from every launch)
+    if (own && ctx->counters_clean && !stats) return RT_OK;
+#endif
+    RT_HIP_TRY(ctx, hipMemsetAsync(counters, 0, kCounterBytes, stream));
+    if (own) ctx->counters_clean = !stats;
+    return RT_OK;
+}
+
 // Enqueues one render.  `fixed` == NULL: the context's own buffers, grown on demand (hipMalloc).  Otherwise the launch
 // is fitted into the given workspace and nothing is allocated: fewer persistent workgroups when the frame stacks of
 // a full grid do not fit, RT_ERR_LIMIT when not even one workgroup or the sample buffer fits.
@@ -459,7 +475,7 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     // has seen it (launch_status), so that two launches without rt_launch_status in between do not lose the first one's
     // abandonment
     RT_HIP_TRY(ctx, hipMemsetAsync(ws.queue, 0, sizeof(unsigned long long), stream));
-    RT_HIP_TRY(ctx, hipMemsetAsync(ws.counters, 0, C_COUNT * sizeof(unsigned long long), stream));
+    if (const int rc = clear_counters(ctx, ws.counters, stats, stream); rc != RT_OK) return rc;
     if (job.sched != nullptr) {
         RT_HIP_TRY(ctx, hipMemsetAsync(job.sched, 0, sched_zero_words * sizeof(uint32_t), stream));
         RT_HIP_TRY(ctx, hipMemsetAsync(job.sched + sched_zero_words, 0xff, sched_list_words * sizeof(uint32_t), stream));
@@ -576,7 +592,7 @@ int deposit_buffers(rt_ctx* ctx, unsigned long long all_roots, unsigned key_bits
 int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t n_parts = 1) {
     if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_photon_generate before rt_scene_upload");
     if (ctx->upload_in_flight && stream != nullptr) RT_HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ev_upload, 0));
-    RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long), stream));
+    if (const int rc = clear_counters(ctx, ctx->d_counters, ctx->collect_stats, stream); rc != RT_OK) return rc;
     RT_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
     if (ctx->photon_steps > 0.0f && ctx->n_slots > 0 && !ctx->point_lights.empty() && ctx->n_phi > 0 && ctx->n_theta > 0) {
         const size_t atlas_bytes = static_cast<size_t>(ctx->n_slots) * ctx->dev.photon_size * ctx->dev.photon_size * sizeof(float4);
@@ -616,10 +632,9 @@ int photon_enqueue(rt_ctx* ctx, hipStream_t stream, uint32_t part = 0, uint32_t 
         job.static_blocks = static_blocks_per_wave(job.n_roots, lanes, RT_STATIC_SHARE_PHOTON);
         job.dyn_base = static_cast<uint64_t>(job.n_waves) * job.static_blocks * 64ull;
         job.id_chunk = id_chunk_for(job.n_roots - job.dyn_base, lanes);
-        job.queue_head = ctx->d_queue;
+        job.queue_head = ctx->d_dep_words + 16;   // a cache line of its own, behind the control words' (not d_queue: its word [1] is the Julia watchdog's sticky flag)
         job.counters = ctx->d_counters;
-        RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), stream));   // the head only: [1] is the Julia watchdog's sticky flag
-        RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_dep_words, 0, 16 * sizeof(unsigned long long), stream));   // every control word of the pass at once
+        RT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_dep_words, 0, 32 * sizeof(unsigned long long), stream));   // every control word of the pass and its queue head at once
         // reference deposit order: record, sort, sum (rt_photon_order.hip) when the key fits 64 bits
         const unsigned long long n_texels = static_cast<unsigned long long>(ctx->n_slots) * ctx->dev.photon_size * ctx->dev.photon_size;
         // a root deposits at most once per leaf of its tree, 2^(max_bounces+1) in theory; when the key has no room for
@@ -838,8 +853,8 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
     }
     ctx->n_cus = prop.multiProcessorCount;
     if (hipMalloc(reinterpret_cast<void**>(&ctx->d_queue), 256) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), C_COUNT * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&ctx->d_dep_words), 16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), kCounterBytes) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&ctx->d_dep_words), 32 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->h_dep_words), 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), 2 * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&ctx->ev_dep) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess ||
@@ -862,7 +877,7 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
         if (const char* e = std::getenv("RT_DENSE_BVH")) ctx->dense_with_bvh = std::atoi(e) != 0;
         if (const char* e = std::getenv("RT_JULIA_GROUP_TILES")) ctx->julia_group_tiles = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
     }
-    (void)hipMemset(ctx->d_counters, 0, C_COUNT * sizeof(unsigned long long));
+    ctx->counters_clean = hipMemset(ctx->d_counters, 0, kCounterBytes) == hipSuccess;
     (void)hipMemset(ctx->d_queue, 0, 256);   // [0] queue head, [1] watchdog flag of trace_julia_kernel
     ctx->h_status[0] = ctx->h_status[1] = 0;
     *out_ctx = ctx;
