@@ -487,6 +487,9 @@ def main():
         rel, t, label = WORKLOADS[args.workload]
         scene = capi.Scene(os.path.join(ROOT, "scenes", rel), t)
     ctx = capi.Context(local_rank)
+    if collective:
+        # RCCL's gather kernels of step i sit on the GPU when step i + 1 is dispatched (include/rt_hip.h, RT_OPT_SHARED_GPU)
+        ctx.set_option(capi.RT_OPT_SHARED_GPU, 1)
     if args.bvh_min is not None:
         ctx.set_option(capi.RT_OPT_BVH_MIN_TRIANGLES, args.bvh_min)
     ctx.upload(scene)
@@ -619,7 +622,7 @@ def main():
                        "shadow_rays_elided_per_frame": stats.get("shadow_rays_elided", 0),   # counted in rays_per_frame (rays of the reference's formulation), not traced: DESIGN.md 4.4
                        "rays_traced_per_frame": rays_traced,   # what the plain launch traces
                        "frames_per_step": world, "sec_per_frame": elapsed / args.steps,
-                       "parallelism": "frames sharded over ranks, RGBA8 frames gathered to rank 0 over RCCL (gather of a step overlaps the next step's render; all gathers complete inside the timed region)" if world > 1 else ("1 GPU, RT_BENCH_FORCE_GATHER: the frame gathered to itself over RCCL" if collective else "1 GPU")},
+                       "parallelism": "frames sharded over ranks, RGBA8 frames gathered to rank 0 over RCCL (gather of a step overlaps the next step's render; all gathers complete inside the timed region; RT_OPT_SHARED_GPU)" if world > 1 else ("1 GPU, RT_BENCH_FORCE_GATHER: the frame gathered to itself over RCCL" if collective else "1 GPU")},
             "roofline": {"bound": "valu", "kernel": "trace_julia_kernel" if scene.desc.n_julias > 0 else "trace_kernel", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": measured_traffic(args.workload),
                          "executed_valu": executed_valu(args.workload, kernel_ms),

@@ -223,11 +223,20 @@ enum {
                                    mirror or of clear glass — and no factor is infinite or NaN (material, lights, point and
                                    normal are checked).  Same picture bit for bit.  rt_stats.shadow_rays still counts such
                                    rays, shadow_rays_elided says how many.  0: trace every shadow ray. */
-    RT_OPT_CULL_PHOTON_ROOTS = 8   /* 1 (default): a root of the photon pass (src/photonmap.cpp:38-58) whose ray misses the box around
+    RT_OPT_CULL_PHOTON_ROOTS = 8,  /* 1 (default): a root of the photon pass (src/photonmap.cpp:38-58) whose ray misses the box around
                                    every object that refracts or reflects light rays is not traced: the reference deposits a light
                                    ray only after such a bounce (src/photonmap.cpp:79-83), so these roots leave nothing.  Same photon
                                    textures bit for bit; rt_stats.photon_segments of a counters launch still counts them and
                                    photon_roots_culled says how many.  0: trace every root. */
+    RT_OPT_SHARED_GPU = 9          /* 0 (default): the GPU is this launch's own while a render runs.  1: kernels of other streams (a
+                                   collective's, another library's) may sit on it when the render is dispatched.  The render is a
+                                   grid sized to fill the GPU whose waves own a share of the tiles outright (no shared counter
+                                   while those last); a workgroup that finds no room at dispatch starts when others END, and the
+                                   frame then waits for its share: C2 1.67 -> 2.00 ms, C3 7.7 -> 9.2 ms beside eight small
+                                   workgroups of another stream, however briefly they stay (tools/coresident_probe.py).  With 1
+                                   every tile goes through the launch's counter instead: C2 1.75 ms alone and 1.75-1.82 beside
+                                   them.  Same picture bit for bit.  Frames of at most two tiles per wave (C5's, which is what
+                                   several contexts per GPU are for) and the photon pass are handed out as before. */
 };
 int rt_set_option(rt_ctx* ctx, int option, int64_t value);
 

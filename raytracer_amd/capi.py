@@ -21,6 +21,7 @@ RT_OPT_COLLECT_STATS, RT_OPT_BVH_MIN_TRIANGLES, RT_OPT_DOF_SEED, RT_OPT_PHOTON_O
 RT_OPT_DEBUG_FORCE_ABORT = 6
 RT_OPT_ELIDE_UNLIT_SHADOWS = 7
 RT_OPT_CULL_PHOTON_ROOTS = 8
+RT_OPT_SHARED_GPU = 9
 RT_DEFAULT_BVH_MIN_TRIANGLES = 48
 FLT_MAX = float(np.finfo(np.float32).max)
 

@@ -170,6 +170,8 @@ struct rt_ctx {
     bool debug_force_abort = false;             // RT_OPT_DEBUG_FORCE_ABORT
     bool elide_unlit_shadows = true;            // RT_OPT_ELIDE_UNLIT_SHADOWS
     bool cull_photon_roots = true;              // RT_OPT_CULL_PHOTON_ROOTS
+    int static_share = -1;                      // sixteenths of a render's tiles that its waves own outright; < 0: the measured defaults
+                                                // (RT_STATIC_SHARE_*).  RT_OPT_SHARED_GPU sets 0; RT_STATIC_SHARE in the environment: developer sweeps
     unsigned long long* status_flag[2] = {nullptr, nullptr};   // device words the pending statuses were copied from (each cleared once seen)
     unsigned char* noalloc_scratch = nullptr;   // address of `scratch` on this context's device (hipGetSymbolAddress)
     // persistent grid of the render kernels for the uploaded scene ([0] plain, [1] counters build): asked once per upload
@@ -460,7 +462,8 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
     // a launch of at most two tiles per wave needs no counter at all (C1: 0.10 -> 0.06 ms)
     const bool tiny = job.n_samples / 64 <= 2 * (id_lanes / 64);
     job.static_blocks = tiny ? static_cast<uint32_t>((job.n_samples / 64 + id_lanes / 64 - 1) / (id_lanes / 64))
-                             : static_blocks_per_wave(job.n_samples, id_lanes, julia ? RT_STATIC_SHARE_JULIA : job.samples_per_pixel > 1 ? RT_STATIC_SHARE_TRACE_SUPERSAMPLED : RT_STATIC_SHARE_TRACE);
+                             : static_blocks_per_wave(job.n_samples, id_lanes, ctx->static_share >= 0 ? static_cast<unsigned>(ctx->static_share)
+                                                      : julia ? RT_STATIC_SHARE_JULIA : job.samples_per_pixel > 1 ? RT_STATIC_SHARE_TRACE_SUPERSAMPLED : RT_STATIC_SHARE_TRACE);
     if (job.sched != nullptr) job.static_blocks = 0;   // every block goes through the counter (and the claim bits)
     job.dyn_base = static_cast<uint64_t>(job.n_waves) * job.static_blocks * 64ull;
     job.stack = ws.stack;
@@ -872,6 +875,7 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
             return rc;
         }
         ctx->noalloc_scratch = static_cast<unsigned char*>(p);
+        if (const char* e = std::getenv("RT_STATIC_SHARE")) ctx->static_share = std::min(16, std::atoi(e));
         if (const char* e = std::getenv("RT_JULIA_HOT_STEPS")) ctx->julia_hot_steps = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
         if (const char* e = std::getenv("RT_PHOTON_ORDER_SORT")) ctx->dep_force_sort = std::atoi(e) != 0;
         if (const char* e = std::getenv("RT_DENSE_BVH")) ctx->dense_with_bvh = std::atoi(e) != 0;
@@ -921,6 +925,7 @@ int rt_set_option(rt_ctx* ctx, int option, int64_t value) {
         case RT_OPT_DEBUG_FORCE_ABORT: ctx->debug_force_abort = value != 0; return RT_OK;
         case RT_OPT_ELIDE_UNLIT_SHADOWS: ctx->elide_unlit_shadows = value != 0; return RT_OK;
         case RT_OPT_CULL_PHOTON_ROOTS: ctx->cull_photon_roots = value != 0; return RT_OK;
+        case RT_OPT_SHARED_GPU: ctx->static_share = value != 0 ? 0 : -1; return RT_OK;
         default: return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
     }
 }

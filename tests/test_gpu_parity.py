@@ -664,6 +664,26 @@ def test_render_rgba8_device_is_render_then_quantize(hip_ctx, source, size, supe
     assert np.array_equal(one[:n].cpu().numpy(), two.cpu().numpy())
 
 
+def test_shared_gpu_option_hands_every_tile_out_through_the_counter_and_changes_no_bit(hip_ctx):
+    """RT_OPT_SHARED_GPU (include/rt_hip.h): no tiles owned outright by the waves.  A frame large enough to have owned
+    tiles (more than two per wave of the grid), with one sample per pixel and with four."""
+    for source, size, supersampling in (("examples/example9.xml", (1280, 720), 1), ("examples/example1.xml", (640, 400), 2)):
+        sc = capi.Scene(scene_path(source), 0.0)
+        sc.set_camera(size[0], size[1], supersampling)
+        hip_ctx.upload(sc)
+        plain, _ = hip_ctx.render()
+        try:
+            hip_ctx.set_option(capi.RT_OPT_SHARED_GPU, 1)
+            shared, _ = hip_ctx.render()
+            bands = capi.Bands(8, 1, 3)
+            part_shared, _ = hip_ctx.render(bands)
+        finally:
+            hip_ctx.set_option(capi.RT_OPT_SHARED_GPU, 0)
+        part, _ = hip_ctx.render(bands)
+        assert np.array_equal(plain.view(np.uint32), shared.view(np.uint32))
+        assert np.array_equal(part.view(np.uint32), part_shared.view(np.uint32))
+
+
 # ---- the callers either side of the path: CLI loops and the driver ---------------------------------
 
 def test_cli_renders_the_caustic_animation_like_the_reference(tmp_path):
