@@ -234,8 +234,8 @@ enum {
                                    while those last); a workgroup that finds no room at dispatch starts when others END, and the
                                    frame then waits for its share: C2 1.67 -> 2.00 ms, C3 7.7 -> 9.2 ms beside eight small
                                    workgroups of another stream, however briefly they stay (tools/coresident_probe.py).  With 1
-                                   every tile goes through the launch's counter instead: C2 1.75 ms alone and 1.75-1.82 beside
-                                   them.  Same picture bit for bit.  Frames of at most two tiles per wave (C5's, which is what
+                                   a wave owns its first tile only and every other tile goes through the launch's counter: C2
+                                   1.71 ms alone and 1.73-1.76 beside them.  Same picture bit for bit.  Frames of at most two tiles per wave (C5's, which is what
                                    several contexts per GPU are for) and the photon pass are handed out as before. */
 };
 int rt_set_option(rt_ctx* ctx, int option, int64_t value);

@@ -171,7 +171,9 @@ struct rt_ctx {
     bool elide_unlit_shadows = true;            // RT_OPT_ELIDE_UNLIT_SHADOWS
     bool cull_photon_roots = true;              // RT_OPT_CULL_PHOTON_ROOTS
     int static_share = -1;                      // sixteenths of a render's tiles that its waves own outright; < 0: the measured defaults
-                                                // (RT_STATIC_SHARE_*).  RT_OPT_SHARED_GPU sets 0; RT_STATIC_SHARE in the environment: developer sweeps
+                                                // (RT_STATIC_SHARE_*); RT_STATIC_SHARE in the environment: developer sweeps
+    bool shared_gpu = false;                    // RT_OPT_SHARED_GPU: a wave owns one tile at most (its first: 3 072 waves asking the counter
+                                                // at once is what the share saves a GPU of one's own; none at all: 1.73 ms alone instead of 1.71)
     unsigned long long* status_flag[2] = {nullptr, nullptr};   // device words the pending statuses were copied from (each cleared once seen)
     unsigned char* noalloc_scratch = nullptr;   // address of `scratch` on this context's device (hipGetSymbolAddress)
     // persistent grid of the render kernels for the uploaded scene ([0] plain, [1] counters build): asked once per upload
@@ -465,6 +467,7 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
                              : static_blocks_per_wave(job.n_samples, id_lanes, ctx->static_share >= 0 ? static_cast<unsigned>(ctx->static_share)
                                                       : julia ? RT_STATIC_SHARE_JULIA : job.samples_per_pixel > 1 ? RT_STATIC_SHARE_TRACE_SUPERSAMPLED : RT_STATIC_SHARE_TRACE);
     if (job.sched != nullptr) job.static_blocks = 0;   // every block goes through the counter (and the claim bits)
+    if (ctx->shared_gpu && !tiny && job.static_blocks > 1) job.static_blocks = 1;   // a late workgroup then owes one tile (include/rt_hip.h)
     job.dyn_base = static_cast<uint64_t>(job.n_waves) * job.static_blocks * 64ull;
     job.stack = ws.stack;
     job.queue_head = ws.queue;
@@ -925,7 +928,7 @@ int rt_set_option(rt_ctx* ctx, int option, int64_t value) {
         case RT_OPT_DEBUG_FORCE_ABORT: ctx->debug_force_abort = value != 0; return RT_OK;
         case RT_OPT_ELIDE_UNLIT_SHADOWS: ctx->elide_unlit_shadows = value != 0; return RT_OK;
         case RT_OPT_CULL_PHOTON_ROOTS: ctx->cull_photon_roots = value != 0; return RT_OK;
-        case RT_OPT_SHARED_GPU: ctx->static_share = value != 0 ? 0 : -1; return RT_OK;
+        case RT_OPT_SHARED_GPU: ctx->shared_gpu = value != 0; return RT_OK;
         default: return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
     }
 }
