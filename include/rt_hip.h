@@ -235,7 +235,8 @@ enum {
                                    frame then waits for its share: C2 1.67 -> 2.00 ms, C3 7.7 -> 9.2 ms beside eight small
                                    workgroups of another stream, however briefly they stay (tools/coresident_probe.py).  With 1
                                    a wave owns its first tile only and every other tile goes through the launch's counter: C2
-                                   1.71 ms alone and 1.73-1.76 beside them.  Same picture bit for bit.  Frames of at most two tiles per wave (C5's, which is what
+                                   1.71 ms alone and 1.73-1.76 beside them (a frame with several samples per pixel keeps six sixteenths
+                                   of its tiles owned instead of ten: C3 8.6-8.9 ms beside them).  Same picture bit for bit.  Frames of at most two tiles per wave (C5's, which is what
                                    several contexts per GPU are for) and the photon pass are handed out as before. */
 };
 int rt_set_option(rt_ctx* ctx, int option, int64_t value);

@@ -467,7 +467,14 @@ int render_enqueue(rt_ctx* ctx, const rt_bands* bands, float4* d_out, hipStream_
                              : static_blocks_per_wave(job.n_samples, id_lanes, ctx->static_share >= 0 ? static_cast<unsigned>(ctx->static_share)
                                                       : julia ? RT_STATIC_SHARE_JULIA : job.samples_per_pixel > 1 ? RT_STATIC_SHARE_TRACE_SUPERSAMPLED : RT_STATIC_SHARE_TRACE);
     if (job.sched != nullptr) job.static_blocks = 0;   // every block goes through the counter (and the claim bits)
-    if (ctx->shared_gpu && !tiny && job.static_blocks > 1) job.static_blocks = 1;   // a late workgroup then owes one tile (include/rt_hip.h)
+    // RT_OPT_SHARED_GPU (include/rt_hip.h; tools/coresident_probe.py).  One sample per pixel: a late workgroup owes one tile.
+    // Several: the samples of a pixel like to be rendered together and the share is worth more than the tail costs — beside
+    // the probe's stand-ins C3 takes 9.0-9.2 ms at the default 10/16, 8.64-8.87 at 6/16 (4/16: 8.76-8.98, 2/16: 9.1-9.3,
+    // one tile: 9.5-9.7)
+    if (ctx->shared_gpu && !tiny && !julia && ctx->static_share < 0) {
+        if (job.samples_per_pixel == 1) job.static_blocks = std::min<uint32_t>(job.static_blocks, 1u);
+        else job.static_blocks = std::min<uint32_t>(job.static_blocks, static_blocks_per_wave(job.n_samples, id_lanes, 6));
+    }
     job.dyn_base = static_cast<uint64_t>(job.n_waves) * job.static_blocks * 64ull;
     job.stack = ws.stack;
     job.queue_head = ws.queue;
