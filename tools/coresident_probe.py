@@ -5,6 +5,12 @@ tools/liboccupier.so holds `blocks` workgroups of 256 lanes with `lds` KB of LDS
 stream; the C2 frame (or the workload given) is rendered on the main stream right behind its launch and timed with events.
 
   tools/coresident_probe.py [workload] [reps]
+      PROBE_HOLD=f       the stand-in stays for f x the render's time alone (default 1.5: it outlives the render)
+      PROBE_SHORT=1      three stand-in shapes instead of seven
+      PROBE_PIPELINED=1  bench.py's N > 1 step instead: the stand-in is enqueued behind an event of render i, render i + 1
+                         follows at once; ms per step with RT_OPT_SHARED_GPU off and on (RT_STATIC_SHARE=n: sixteenths of the
+                         tiles owned, developer override of both)
+  build the stand-in first: hipcc -O2 --offload-arch=gfx950 -shared -fPIC tools/occupier.hip -o tools/liboccupier.so
 
 Prints the render time alone and beside each occupier shape.  trace_kernel is a persistent grid sized to fill the GPU
 (three workgroups per CU at C2): a workgroup that finds no room starts when another ends, i.e. at the end of the frame,
