@@ -512,7 +512,12 @@ def main(argv=None):
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     try:
-        render_scene_file(HipRenderer(local_rank), args.scene, args.out)
+        renderer = HipRenderer(local_rank)
+        if world > 1:
+            # the gather of one unit runs beside the render of the next: its kernels sit on the GPU when that grid is
+            # dispatched (include/rt_hip.h, RT_OPT_SHARED_GPU; frames as small as C5's are not affected either way)
+            renderer.ctx.set_option(capi.RT_OPT_SHARED_GPU, 1)
+        render_scene_file(renderer, args.scene, args.out)
     finally:
         if world > 1:
             dist.destroy_process_group()
