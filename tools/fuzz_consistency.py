@@ -2,7 +2,8 @@
 """Developer tool (GPU box): tools/fuzz_consistency.py FIRST LAST  -> on the seeded random scenes of tests/mesh_scene.py, the
 HIP path against ITSELF through its other doors (no oracle, so thousands of scenes per minute): the whole picture against
 the picture assembled from rt_bands{8, r, 3} for r = 0..2, against rt_render_device_noalloc, against a second render,
-against rt_render_rgba8_device (Color::scaleOut of it), and the photon textures of two passes.  Everything must be the same bits."""
+against rt_render_rgba8_device (Color::scaleOut of it), against a render under RT_OPT_SHARED_GPU, and the photon textures
+of two passes.  Everything must be the same bits."""
 import os
 import pathlib
 import sys
@@ -55,6 +56,13 @@ def main():
         except capi.RtError as e:
             if "exceed" not in str(e) and "fit" not in str(e):      # (a frame beyond the fixed workspace is a documented limit)
                 why.append("noalloc: %s" % e)
+        ctx.set_option(capi.RT_OPT_SHARED_GPU, 1)
+        try:
+            shared, _ = ctx.render()
+        finally:
+            ctx.set_option(capi.RT_OPT_SHARED_GPU, 0)
+        if not np.array_equal(img.view(np.uint32), shared.view(np.uint32)):
+            why.append("RT_OPT_SHARED_GPU")
         out8 = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
         ctx.render_rgba8_device(out8.data_ptr())
         torch.cuda.synchronize()
