@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): tools/fuzz_consistency.py FIRST LAST  -> on the seeded random scenes of tests/mesh_scene.py, the
+"""Developer tool (GPU box): tools/fuzz_consistency.py FIRST LAST [WxH]  -> on the seeded random scenes of tests/mesh_scene.py, the
 HIP path against ITSELF through its other doors (no oracle, so thousands of scenes per minute): the whole picture against
 the picture assembled from rt_bands{8, r, 3} for r = 0..2, against rt_render_device_noalloc, against a second render,
 against rt_render_rgba8_device (Color::scaleOut of it), against a render under RT_OPT_SHARED_GPU, and the photon textures
@@ -29,6 +29,9 @@ def main():
         if os.environ.get("FUZZ_TRACE"):
             print("begin seed", seed, flush=True)
         sc = capi.Scene(mesh_scene.write_random_scene(tmp, seed), 0.0)
+        if len(sys.argv) > 3:       # larger pictures (WxH): more tiles than two per wave, so owned tiles and the counter both run
+            w_, h_ = (int(v) for v in sys.argv[3].split("x"))
+            sc.set_camera(w_, h_, 0)
         ctx.upload(sc)
         ctx.photon_generate()
         tex = [ctx.photon_download(o).copy() for o in range(sc.desc.n_objects)] if sc.desc.photon_steps > 0 else []
